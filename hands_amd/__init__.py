@@ -1,0 +1,12 @@
+"""hands_amd -- MI355X-native forward path of the WildHands hand-mesh regressor.
+
+Host side mirrors the reference's module API (``HandsLight``, ``xdict``); compute is
+``libhands_hip.so`` (hand-written gfx950 HIP, see include/hands_hip.h).
+"""
+from .xdict import xdict, prefix_dict  # noqa: F401
+from .hands_light import HandsLight, DEFAULT_ARGS  # noqa: F401
+from .mano import ManoAsset, synthetic_mano_asset, build_mano_asset  # noqa: F401
+from .weights import apply_recipe, synthetic_inputs  # noqa: F401
+
+__all__ = ["HandsLight", "DEFAULT_ARGS", "xdict", "prefix_dict", "ManoAsset", "synthetic_mano_asset",
+           "build_mano_asset", "apply_recipe", "synthetic_inputs"]

@@ -1,0 +1,84 @@
+"""ctypes binding of ``libhands_hip.so`` (declared in include/hands_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or cannot be loaded,
+:func:`lib` raises and every op of :mod:`hands_amd` fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhands_hip.so")
+
+c_float_p = C.c_void_p  # raw device pointers travel as integers
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "B", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad",
+        "in_pix_stride", "out_pix_stride", "res_pix_stride", "Kpad", "relu")]
+
+
+class ManoConsts(C.Structure):
+    _fields_ = [("pose_mean", C.c_void_p), ("J_template", C.c_void_p), ("J_shapedirs", C.c_void_p),
+                ("lbs_weights", C.c_void_p), ("tip_ids", C.c_void_p)]
+
+
+class ManoOut(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("joints3d", C.c_void_p), ("v3d_cam", C.c_void_p),
+                ("j3d_cam", C.c_void_p), ("j2d_norm", C.c_void_p), ("cam_t", C.c_void_p)]
+
+
+# name -> argtypes; every function returns int (0 = ok) except the two noted below
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+SIGNATURES = {
+    "hands_conv2d_nhwc_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P],
+    "hands_nchw3_to_nhwc4_f32": [_P, _P, _I, _I, _I, _P],
+    "hands_maxpool3x3s2_nhwc_f32": [_P, _P, _I, _I, _I, _I, _P],
+    "hands_sumpool_nhwc_f32": [_P, _P, _I, _I, _I, _I, _P],
+    "hands_kpe_concat_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "hands_hmr_init_f32": [_P, _P, _I, _I, _I, _P],
+    "hands_rot6d_to_matrix_f32": [_P, _I, _P, _I, _P],
+    "hands_flip_swap_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "hands_grasp_input_f32": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "hands_mano_pose_f32": [C.POINTER(ManoConsts), _P, _P, _I, _P, _I, _P, _P, _I, _P],
+    "hands_mano_skin_f32": [C.POINTER(ManoConsts), _P, _I, _P, _P, _P, _P, _F, _F, C.POINTER(ManoOut), _I, _P],
+}
+EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string")
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raise if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"hands_amd: {LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C hands_amd/csrc`. There is no CPU fallback.")
+    h = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(h, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    h.hands_abi_version.restype = C.c_int
+    h.hands_error_string.restype = C.c_char_p
+    h.hands_error_string.argtypes = [C.c_int]
+    _lib = h
+    return h
+
+
+def check(code: int, what: str = ""):
+    if code != 0:
+        msg = lib().hands_error_string(code).decode()
+        raise RuntimeError(f"hands_amd: {what} failed with code {code}: {msg}")
+
+
+def ptr(t, offset_elems: int = 0):
+    """Device pointer of a torch tensor (optionally offset by elements), or None."""
+    if t is None:
+        return None
+    return t.data_ptr() + offset_elems * t.element_size()

@@ -1,0 +1,261 @@
+// conv_igemm.hip -- NHWC convolution / linear layer as an implicit GEMM on the gfx950 fp32 matrix
+// cores (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD).
+//
+// GEMM view:  D[n, m] = sum_k W[n, k] * X[m, k]      (n = output channel, m = output pixel)
+// The weight tile is the MFMA "A" operand and the activation tile the "B" operand, so the
+// accumulator of a lane holds 4 CONSECUTIVE output channels of one pixel -> 16-byte NHWC stores.
+//
+// Block tile = (64*WAVES_M pixels) x (64*WAVES_N channels), 4 waves, each wave a 64x64 tile made of
+// 2x2 MFMA 32x32 blocks (64 accumulator registers).  K is walked in steps of 16 floats (64 B per
+// row); tiles are staged global -> registers -> LDS with a two-deep LDS ring, the global loads of
+// step t+1 in flight under the 32 MFMAs (2048 matrix-pipe cycles) of step t.  LDS rows are padded
+// to 20 floats so that both the 16-byte staging writes and the ds_read_b128 fragment reads are
+// bank-conflict free.  Within a 16-wide k-step the k index is permuted (lane half h reads k =
+// 8*kk + 4*h + t for MFMA t): both operands use the same permutation, so the sum is unchanged.
+//
+// Replaces: F.conv2d + eval BatchNorm2d (folded) + ReLU + residual add of
+// src/nets/backbone/resnet.py:134-154,264-280; feature_conv (src/models/hands_light/model.py:91-101);
+// every nn.Linear of the heads.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hands_hip.h"
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;         // floats per k-step
+constexpr int LDS_ROW = 20;    // padded LDS row (floats): 80 B = 5 x 16 B slots
+
+struct ConvArgs {
+  const float* __restrict__ in;
+  const float* __restrict__ w;
+  const float* __restrict__ bias;
+  const float* res;   // may alias out (in-place residual update of the HMR state)
+  float* out;
+  int M, N, Kpad;
+  int H, W, Cin, Ho, Wo, KH, KW, stride, pad;
+  int in_ps, out_ps, res_ps;
+  int relu;
+  int nblk_m, nblk_n;
+};
+
+// XCD-aware block remap: blocks are dispatched round-robin over the 8 XCDs (private L2 each);
+// give every XCD a contiguous range of tiles so that the n-tiles of one m-tile share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+template <int WAVES_M, int WAVES_N, bool STEM>
+__global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
+  constexpr int BM = 64 * WAVES_M;
+  constexpr int BN = 64 * WAVES_N;
+  constexpr int A_ROWS = BM / 64;   // activation rows staged per thread
+  constexpr int W_ROWS = BN / 64;   // weight rows staged per thread
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_ROW];
+  float* sX = lds;                          // [2][BM][LDS_ROW]
+  float* sW = lds + 2 * BM * LDS_ROW;       // [2][BN][LDS_ROW]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N;            // wave row (pixels)
+  const int wn = wave % WAVES_N;            // wave col (channels)
+
+  const int tile = xcd_remap(blockIdx.x, a.nblk_m * a.nblk_n);
+  const int m0 = (tile / a.nblk_n) * BM;    // n fastest: consecutive tiles share the pixel rows
+  const int n0 = (tile % a.nblk_n) * BN;
+
+  // ---- per-thread staging assignment: row = (tid>>2) + 64*i, 16-byte chunk = tid&3 ------------
+  const int srow = tid >> 2;
+  const int chunk = tid & 3;
+  int x_base[A_ROWS];     // float offset of pixel (b, ho*s-pad, wo*s-pad) channel 0 (may be "negative")
+  int x_hi0[A_ROWS], x_wi0[A_ROWS];
+  bool x_ok[A_ROWS];
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int i = 0; i < A_ROWS; ++i) {
+    const int m = m0 + srow + 64 * i;
+    x_ok[i] = m < a.M;
+    const int mm = x_ok[i] ? m : 0;
+    const int b = mm / HoWo;
+    const int rem = mm - b * HoWo;
+    const int ho = rem / a.Wo;
+    const int wo = rem - ho * a.Wo;
+    x_hi0[i] = ho * a.stride - a.pad;
+    x_wi0[i] = wo * a.stride - a.pad;
+    x_base[i] = ((b * a.H + x_hi0[i]) * a.W + x_wi0[i]) * a.in_ps;
+  }
+  const float* wrow[W_ROWS];
+#pragma unroll
+  for (int i = 0; i < W_ROWS; ++i) wrow[i] = a.w + (size_t)(n0 + srow + 64 * i) * a.Kpad + chunk * 4;
+
+  float4 xr[A_ROWS], wr[W_ROWS];
+  // k-step state (wave-uniform for the regular path)
+  int kh = 0, kw = 0, c0 = 0;
+  const int ntaps = a.KH * a.KW;
+
+  auto load_tiles = [&](int kt) {
+    if constexpr (STEM) {
+      // Cin == 4: every 16-byte chunk is its own filter tap
+      const int tap = kt * 4 + chunk;
+      const int tkh = tap / a.KW;
+      const int tkw = tap - tkh * a.KW;
+      const int toff = (tkh * a.W + tkw) * a.in_ps;
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        const bool ok = x_ok[i] && tap < ntaps && (unsigned)(x_hi0[i] + tkh) < (unsigned)a.H &&
+                        (unsigned)(x_wi0[i] + tkw) < (unsigned)a.W;
+        xr[i] = ok ? *reinterpret_cast<const float4*>(a.in + (x_base[i] + toff))
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      const int toff = (kh * a.W + kw) * a.in_ps + c0 + chunk * 4;
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        const bool ok = x_ok[i] && (unsigned)(x_hi0[i] + kh) < (unsigned)a.H &&
+                        (unsigned)(x_wi0[i] + kw) < (unsigned)a.W;
+        xr[i] = ok ? *reinterpret_cast<const float4*>(a.in + (x_base[i] + toff))
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      c0 += BK;
+      if (c0 >= a.Cin) { c0 = 0; if (++kw == a.KW) { kw = 0; ++kh; } }
+    }
+#pragma unroll
+    for (int i = 0; i < W_ROWS; ++i) wr[i] = *reinterpret_cast<const float4*>(wrow[i] + kt * BK);
+  };
+  auto store_tiles = [&](int buf) {
+    float* dx = sX + buf * BM * LDS_ROW + srow * LDS_ROW + chunk * 4;
+    float* dw = sW + buf * BN * LDS_ROW + srow * LDS_ROW + chunk * 4;
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) *reinterpret_cast<float4*>(dx + 64 * i * LDS_ROW) = xr[i];
+#pragma unroll
+    for (int i = 0; i < W_ROWS; ++i) *reinterpret_cast<float4*>(dw + 64 * i * LDS_ROW) = wr[i];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = a.Kpad / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  // fragment read offsets: row = lane&31, k half = lane>>5
+  const int frag = (lane & 31) * LDS_ROW + (lane >> 5) * 4;
+  const float* fw = sW + (wn * 64) * LDS_ROW + frag;
+  const float* fx = sX + (wm * 64) * LDS_ROW + frag;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);   // in flight under this step's MFMAs
+
+    float4 wf[2][2], xf[2][2];              // [32-row block][kk]
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        wf[i][kk] = *reinterpret_cast<const float4*>(fw + buf * BN * LDS_ROW + i * 32 * LDS_ROW + kk * 8);
+        xf[i][kk] = *reinterpret_cast<const float4*>(fx + buf * BM * LDS_ROW + i * 32 * LDS_ROW + kk * 8);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float wv = reinterpret_cast<const float*>(&wf[i][kk])[t];
+            const float xv = reinterpret_cast<const float*>(&xf[j][kk])[t];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, xv, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D row = channel = 8*q + 4*(lane>>5) + e, D col = pixel = lane&31 ---------------
+  const int half = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + wm * 64 + j * 32 + (lane & 31);
+    if (m >= a.M) continue;
+    float* orow = a.out + (size_t)m * a.out_ps;
+    const float* rrow = a.res ? a.res + (size_t)m * a.res_ps : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + i * 32 + q * 8 + half * 4;
+        if (n >= a.N) continue;
+        const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+        float4 v;
+        v.x = acc[i][j][q * 4 + 0] + bv.x;
+        v.y = acc[i][j][q * 4 + 1] + bv.y;
+        v.z = acc[i][j][q * 4 + 2] + bv.z;
+        v.w = acc[i][j][q * 4 + 3] + bv.w;
+        if (rrow) {
+          const float4 rv = *reinterpret_cast<const float4*>(rrow + n);
+          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        if (a.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(orow + n) = v;
+      }
+    }
+  }
+}
+
+template <int WAVES_M, int WAVES_N, bool STEM>
+int launch(ConvArgs& a, hipStream_t stream) {
+  constexpr int BM = 64 * WAVES_M, BN = 64 * WAVES_N;
+  a.nblk_m = (a.M + BM - 1) / BM;
+  a.nblk_n = (a.N + BN - 1) / BN;
+  const long long nwg = (long long)a.nblk_m * a.nblk_n;
+  if (nwg <= 0 || nwg > 0x7fffffffLL) return HANDS_EINVAL;
+  hipLaunchKernelGGL((conv_igemm_f32_kernel<WAVES_M, WAVES_N, STEM>), dim3((unsigned)nwg), dim3(256), 0,
+                     stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
+                                     const float* bias, const float* residual, float* out,
+                                     hands_stream_t stream) {
+  if (!d || !in || !w_packed || !bias || !out) return HANDS_EINVAL;
+  if (d->B <= 0 || d->Cin % 4 || d->Cout % 4 || d->Kpad % BK || d->Kpad < d->KH * d->KW * d->Cin)
+    return HANDS_EINVAL;
+  const bool stem = d->Cin == 4;
+  if (!stem && d->Cin % 16) return HANDS_EINVAL;
+  if (d->in_pix_stride < d->Cin || d->out_pix_stride < d->Cout) return HANDS_EINVAL;
+  // offsets are kept in 32-bit float units inside the kernel
+  const long long in_elems = (long long)d->B * d->H * d->W * d->in_pix_stride;
+  if (in_elems >= (1LL << 31)) return HANDS_EINVAL;
+  ConvArgs a;
+  a.in = in; a.w = w_packed; a.bias = bias; a.res = residual; a.out = out;
+  a.M = d->B * d->Ho * d->Wo; a.N = d->Cout; a.Kpad = d->Kpad;
+  a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+  a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
+  a.relu = d->relu;
+  hipStream_t s = (hipStream_t)stream;
+  if (stem) return (d->Cout <= 64) ? launch<4, 1, true>(a, s) : launch<2, 2, true>(a, s);
+  return (d->Cout <= 64) ? launch<4, 1, false>(a, s) : launch<2, 2, false>(a, s);
+}

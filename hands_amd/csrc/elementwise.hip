@@ -1,0 +1,271 @@
+// elementwise.hip -- the HBM-bound glue kernels of the hands_light forward path (gfx950).
+// Layout conversion, max-pool, sum-pool, key-point-encoding concat, HMR state init, 6D->matrix,
+// flip/swap, grasp-input assembly.  All are streaming kernels: 16-byte accesses, consecutive lanes
+// on consecutive addresses, grid-stride over <= 2048 blocks.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hands_hip.h"
+#include "common.h"
+#include "rot_device.h"
+
+namespace {
+
+// ---- (B,3,H,W) -> (B,H,W,4) ----------------------------------------------------------------------
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ in, float4* __restrict__ out,
+                                      long long npix_total, int HW) {
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix_total;
+       p += (long long)gridDim.x * blockDim.x) {
+    const long long b = p / HW;
+    const int r = (int)(p - b * HW);
+    const float* src = in + b * 3LL * HW + r;
+    out[p] = make_float4(src[0], src[HW], src[2LL * HW], 0.f);
+  }
+}
+
+// ---- MaxPool 3x3 s2 p1, NHWC, 4 channels per thread ---------------------------------------------
+__global__ void maxpool3x3s2_kernel(const float4* __restrict__ in, float4* __restrict__ out, int B,
+                                    int H, int W, int C4, int Ho, int Wo) {
+  const long long total = (long long)B * Ho * Wo * C4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long long t = i / C4;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int hi = ho * 2 - 1 + dh;
+      if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int wi = wo * 2 - 1 + dw;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        const float4 v = in[((long long)(b * H + hi) * W + wi) * C4 + c];
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    out[i] = m;
+  }
+}
+
+// ---- feat_vec[b,c] = sum_p feat[b,p,c] ------------------------------------------------------------
+__global__ void sumpool_kernel(const float4* __restrict__ in, float* __restrict__ out, int B, int HW,
+                               int C4, int out_stride) {
+  const int total = B * C4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int b = i / C4, c = i - b * C4;
+    const float4* src = in + (long long)b * HW * C4 + c;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < HW; ++p) {
+      const float4 v = src[(long long)p * C4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + (long long)b * out_stride + c * 4) = s;
+  }
+}
+
+// ---- cat([crop+glb, center_enc, corner_enc]) ------------------------------------------------------
+// encoding element e of an angle vector with nc components: layout (L, nc, 2): k = e/(2nc),
+// ci = (e/2)%nc, sc = e&1 -> sin/cos(2^k * angle[ci])            (model.py:444-460)
+__device__ __forceinline__ float kpe_elem(const float* ang, int nc, int e) {
+  const int sc = e & 1, ci = (e >> 1) % nc, k = (e >> 1) / nc;
+  const float x = (float)(1 << k) * ang[ci];
+  return sc ? cosf(x) : sinf(x);
+}
+
+__global__ void kpe_concat_kernel(const float4* __restrict__ crop, const float4* __restrict__ glb,
+                                  const float* __restrict__ center, const float* __restrict__ corner,
+                                  float4* __restrict__ out, int B2, int Bg, int HW, int C4, int L) {
+  const int nce = 4 * L, nco = 16 * L;          // 2*L*2, 2*L*8
+  const int Co4 = C4 + (nce + nco) / 4;
+  const long long total = (long long)B2 * HW * Co4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Co4);
+    const long long pix = i / Co4;              // b2*HW + p
+    const int b2 = (int)(pix / HW);
+    const int p = (int)(pix - (long long)b2 * HW);
+    float4 v;
+    if (c < C4) {
+      const float4 a = crop[pix * C4 + c];
+      const float4 g = glb[((long long)(b2 % Bg) * HW + p) * C4 + c];
+      v = make_float4(a.x + g.x, a.y + g.y, a.z + g.z, a.w + g.w);
+    } else {
+      const int e0 = (c - C4) * 4;
+      float r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u;
+        r[u] = e < nce ? kpe_elem(center + b2 * 2, 2, e) : kpe_elem(corner + b2 * 8, 8, e - nce);
+      }
+      v = make_float4(r[0], r[1], r[2], r[3]);
+    }
+    out[i] = v;
+  }
+}
+
+// ---- HMR state init --------------------------------------------------------------------------------
+// row layout (ld = F + 112): [feat F | pose6d 96 | shape 10 | 0 0 | cam 3 | 0]
+__global__ void hmr_init_kernel(float* __restrict__ state, const float* __restrict__ cam_init, int B,
+                                int ld, int F) {
+  const int total = B * 112;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int b = i / 112, e = i - b * 112;
+    float v = 0.f;
+    if (e < 96) { const int r = e % 6; v = (r == 0 || r == 4) ? 1.f : 0.f; }   // identity 6D
+    else if (e >= 108 && e < 111) v = cam_init[b * 4 + (e - 108)];
+    state[(long long)b * ld + F + e] = v;
+  }
+}
+
+// ---- rotation_6d_to_matrix (rows) ------------------------------------------------------------------
+__global__ void rot6d_kernel(const float* __restrict__ pose6d, int ld6, float* __restrict__ rotmat,
+                             int B) {
+  const int total = B * 16;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int b = i >> 4, j = i & 15;
+    const float* s = pose6d + (long long)b * ld6 + j * 6;
+    const float a1x = s[0], a1y = s[1], a1z = s[2], a2x = s[3], a2y = s[4], a2z = s[5];
+    // F.normalize: x / max(||x||, 1e-12)
+    float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
+    const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+    const float d = b1x * a2x + b1y * a2y + b1z * a2z;
+    float b2x = a2x - d * b1x, b2y = a2y - d * b1y, b2z = a2z - d * b1z;
+    float n2 = fmaxf(sqrtf(b2x * b2x + b2y * b2y + b2z * b2z), 1e-12f);
+    b2x /= n2; b2y /= n2; b2z /= n2;
+    float* o = rotmat + (long long)i * 9;
+    o[0] = b1x; o[1] = b1y; o[2] = b1z;
+    o[3] = b2x; o[4] = b2y; o[5] = b2z;
+    o[6] = b1y * b2z - b1z * b2y; o[7] = b1z * b2x - b1x * b2z; o[8] = b1x * b2y - b1y * b2x;
+  }
+}
+
+// ---- is_flipped swap (model.py:341-368) -------------------------------------------------------------
+__global__ void flip_swap_kernel(const int64_t* __restrict__ flipped, const float* __restrict__ rotmat,
+                                 const float* __restrict__ shape, const float* __restrict__ cam,
+                                 const float* __restrict__ cam_init, float* __restrict__ rotmat_o,
+                                 float* __restrict__ shape_o, float* __restrict__ cam_o,
+                                 float* __restrict__ cam_init_o, int Bg) {
+  const int total = 2 * Bg * 16;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int row = i >> 4, j = i & 15;         // row in [0,2Bg): right rows then left rows
+    const int b = row % Bg;
+    const bool f = flipped[b] != 0;
+    const int src = f ? (row < Bg ? row + Bg : row - Bg) : row;   // take the other hand when flipped
+    const float* m = rotmat + ((long long)src * 16 + j) * 9;
+    float* o = rotmat_o + ((long long)row * 16 + j) * 9;
+    if (f) {
+      float aa[3];
+      hands::matrix_to_axis_angle(m, aa);
+      aa[1] = -aa[1]; aa[2] = -aa[2];
+      hands::axis_angle_to_matrix(aa, o);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 9; ++e) o[e] = m[e];
+    }
+    if (j < 10) shape_o[row * 10 + j] = shape[src * 10 + j];
+    if (j < 3) {
+      const float sg = (f && j == 1) ? -1.f : 1.f;   // * [1,-1,1]
+      cam_o[row * 3 + j] = cam[src * 3 + j] * sg;
+      cam_init_o[row * 3 + j] = cam_init[src * 3 + j] * sg;
+    }
+  }
+}
+
+// ---- grasp-head input rows: [feat_vec F | rotmat 144 | shape 10 | 0-pad] ------------------------------
+__global__ void grasp_input_kernel(const float* __restrict__ shape, int ld_shape,
+                                   const float* __restrict__ rotmat, const float* __restrict__ feat_vec,
+                                   float* __restrict__ out, int B2, int Bg, int F, int ld_out) {
+  const long long total = (long long)B2 * ld_out;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / ld_out), e = (int)(i - (long long)b * ld_out);
+    float v = 0.f;
+    if (e < F) v = feat_vec[(long long)(b % Bg) * F + e];
+    else if (e < F + 144) v = rotmat[(long long)b * 144 + (e - F)];
+    else if (e < F + 154) v = shape[(long long)b * ld_shape + (e - F - 144)];
+    out[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int hands_nchw3_to_nhwc4_f32(const float* in, float* out, int B, int H, int W, hands_stream_t stream) {
+  if (!in || !out || B <= 0) return HANDS_EINVAL;
+  const long long n = (long long)B * H * W;
+  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(hands_grid_1d(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, in, (float4*)out, n, H * W);
+  HANDS_LAUNCH_CHECK();
+}
+
+int hands_maxpool3x3s2_nhwc_f32(const float* in, float* out, int B, int H, int W, int C,
+                                hands_stream_t stream) {
+  if (!in || !out || B <= 0 || C % 4) return HANDS_EINVAL;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long n = (long long)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(hands_grid_1d(n, 256, 256 * 16)), dim3(256), 0,
+                     (hipStream_t)stream, (const float4*)in, (float4*)out, B, H, W, C / 4, Ho, Wo);
+  HANDS_LAUNCH_CHECK();
+}
+
+int hands_sumpool_nhwc_f32(const float* feat, float* out, int B, int HW, int C, int out_stride,
+                           hands_stream_t stream) {
+  if (!feat || !out || B <= 0 || C % 4 || out_stride % 4) return HANDS_EINVAL;
+  hipLaunchKernelGGL(sumpool_kernel, dim3(hands_grid_1d((long long)B * C / 4, 64)), dim3(64), 0,
+                     (hipStream_t)stream, (const float4*)feat, out, B, HW, C / 4, out_stride);
+  HANDS_LAUNCH_CHECK();
+}
+
+int hands_kpe_concat_f32(const float* crop, const float* glb, const float* center_angle,
+                         const float* corner_angle, float* out, int B2, int Bg, int HW, int C,
+                         int n_freq, hands_stream_t stream) {
+  if (!crop || !glb || !center_angle || !corner_angle || !out || B2 <= 0 || Bg <= 0 || C % 4 ||
+      n_freq < 1 || n_freq > 16)
+    return HANDS_EINVAL;
+  const long long n = (long long)B2 * HW * (C / 4 + 5 * n_freq);
+  hipLaunchKernelGGL(kpe_concat_kernel, dim3(hands_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)crop, (const float4*)glb, center_angle, corner_angle, (float4*)out,
+                     B2, Bg, HW, C / 4, n_freq);
+  HANDS_LAUNCH_CHECK();
+}
+
+int hands_hmr_init_f32(float* state, const float* cam_init, int B, int ld, int F, hands_stream_t stream) {
+  if (!state || !cam_init || B <= 0 || ld < F + 112) return HANDS_EINVAL;
+  hipLaunchKernelGGL(hmr_init_kernel, dim3(hands_grid_1d((long long)B * 112, 256)), dim3(256), 0,
+                     (hipStream_t)stream, state, cam_init, B, ld, F);
+  HANDS_LAUNCH_CHECK();
+}
+
+int hands_rot6d_to_matrix_f32(const float* pose6d, int ld6, float* rotmat, int B, hands_stream_t stream) {
+  if (!pose6d || !rotmat || B <= 0) return HANDS_EINVAL;
+  hipLaunchKernelGGL(rot6d_kernel, dim3(hands_grid_1d((long long)B * 16, 256)), dim3(256), 0,
+                     (hipStream_t)stream, pose6d, ld6, rotmat, B);
+  HANDS_LAUNCH_CHECK();
+}
+
+int hands_flip_swap_f32(const int64_t* is_flipped, const float* rotmat, const float* shape,
+                        const float* cam, const float* cam_init, float* rotmat_out, float* shape_out,
+                        float* cam_out, float* cam_init_out, int Bg, hands_stream_t stream) {
+  if (!is_flipped || !rotmat || !shape || !cam || !cam_init || !rotmat_out || !shape_out || !cam_out ||
+      !cam_init_out || Bg <= 0)
+    return HANDS_EINVAL;
+  hipLaunchKernelGGL(flip_swap_kernel, dim3(hands_grid_1d((long long)Bg * 32, 256)), dim3(256), 0,
+                     (hipStream_t)stream, is_flipped, rotmat, shape, cam, cam_init, rotmat_out,
+                     shape_out, cam_out, cam_init_out, Bg);
+  HANDS_LAUNCH_CHECK();
+}
+
+int hands_grasp_input_f32(const float* shape, int ld_shape, const float* rotmat, const float* feat_vec,
+                          float* out, int B2, int Bg, int F, int ld_out, hands_stream_t stream) {
+  if (!shape || !rotmat || !feat_vec || !out || B2 <= 0 || Bg <= 0 || ld_out < F + 154)
+    return HANDS_EINVAL;
+  hipLaunchKernelGGL(grasp_input_kernel, dim3(hands_grid_1d((long long)B2 * ld_out, 256)), dim3(256), 0,
+                     (hipStream_t)stream, shape, ld_shape, rotmat, feat_vec, out, B2, Bg, F, ld_out);
+  HANDS_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -1,0 +1,448 @@
+"""``HandsLight`` -- the WildHands forward path on MI355X, behind the reference's module API.
+
+Same constructor, ``forward(inputs, meta_info) -> xdict`` contract, 22 output keys and
+``state_dict`` names as the reference model (src/models/hands_light/model.py:15-437), but every
+statement of ``forward`` runs as a hand-written gfx950 kernel from ``libhands_hip.so``:
+
+    statement (model.py)                      kernel (include/hands_hip.h)
+    :193,238-239  ResNet-50 trunks            hands_conv2d_nhwc_f32 (fp32 MFMA implicit GEMM, BN folded,
+                                              bias/residual/ReLU epilogue), hands_maxpool3x3s2_nhwc_f32
+    :196          sum-pool                    hands_sumpool_nhwc_f32
+    :258-271      KPE + concat                hands_kpe_concat_f32
+    :313-314      feature_conv                hands_conv2d_nhwc_f32 x4
+    :320-321      HandHMR x2                  hands_conv2d_nhwc_f32 (cam_init, 3 x refine+decoders),
+                                              hands_hmr_init_f32, hands_rot6d_to_matrix_f32
+    :341-368      is_flipped swap             hands_flip_swap_f32 (per sample, no host sync)
+    :378-390      MANOHead x2                 hands_mano_pose_f32, blend GEMM, hands_mano_skin_f32
+    :401-404      grasp classifier            hands_grasp_input_f32, hands_conv2d_nhwc_f32 x4
+
+torch is used for parameter containers, device buffers and streams only.  The default shipped
+configuration is supported (resnet50, pos_enc='center+corner_latent', use_glb_feat, shared hand
+backbone, tf_decoder=False, grasp head on); other switches raise ``NotImplementedError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import ConvDesc, ManoConsts, ManoOut, check, ptr
+from .mano import ManoLayer, build_mano_asset
+from .packing import (HMR_VEC, PackedConv, fold_bn, hmr_state_columns, pack_conv, pack_linear,
+                      pack_mano)
+from .xdict import prefix_dict, xdict
+
+RESNET50_LAYERS = (3, 4, 6, 3)
+
+
+# --------------------------------------------------------------------------------------------------
+# parameter containers (names = the reference's state_dict keys; never called)
+# --------------------------------------------------------------------------------------------------
+class _Bottleneck(nn.Module):
+    """resnet.py:99-154 parameter layout (conv1/bn1/conv2/bn2/conv3/bn3/downsample.{0,1})."""
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.stride = stride
+        if downsample:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                                            nn.BatchNorm2d(planes * 4))
+        else:
+            self.downsample = None
+
+
+class ResNet50Params(nn.Module):
+    """resnet.py:157-280 parameter layout of the ResNet-50 trunk (no avgpool/fc)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        inplanes = 64
+        for li, (planes, n) in enumerate(zip((64, 128, 256, 512), RESNET50_LAYERS), start=1):
+            blocks = []
+            for bi in range(n):
+                stride = 2 if (bi == 0 and li > 1) else 1
+                blocks.append(_Bottleneck(inplanes, planes, stride, downsample=(bi == 0)))
+                inplanes = planes * 4
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+
+
+class _HMRLayerParams(nn.Module):
+    """hmr_layer.py:7-62 (tf_decoder=False)."""
+
+    def __init__(self, feat_dim, mid_dim, specs):
+        super().__init__()
+        hmr_dim = feat_dim + sum(specs.values())
+        self.refine = nn.Sequential(nn.Linear(hmr_dim, mid_dim), nn.ReLU(), nn.Dropout(),
+                                    nn.Linear(mid_dim, mid_dim), nn.ReLU(), nn.Dropout())
+        self.decoders = nn.ModuleDict({k: nn.Linear(mid_dim, v) for k, v in specs.items()})
+
+
+class HandHMR(nn.Module):
+    """hand_hmr.py:9-44 parameter layout."""
+
+    def __init__(self, feat_dim, is_rhand, n_iter):
+        super().__init__()
+        self.is_rhand, self.n_iter = is_rhand, n_iter
+        self.hand_specs = {"pose_6d": 96, "cam_t/wp": 3, "shape": 10}
+        self.hmr_layer = _HMRLayerParams(feat_dim, 1024, self.hand_specs)
+        self.cam_init = nn.Sequential(nn.Linear(feat_dim, 512), nn.ReLU(), nn.Linear(512, 512), nn.ReLU(),
+                                      nn.Linear(512, 3))
+
+
+class MANOHead(nn.Module):
+    """mano_head.py:12-19: holds the MANO layer as ``.mano``."""
+
+    def __init__(self, is_rhand, focal_length, img_res, asset=None):
+        super().__init__()
+        self.mano = ManoLayer(asset if asset is not None else build_mano_asset(is_rhand))
+        self.focal_length, self.img_res, self.is_rhand = focal_length, img_res, is_rhand
+
+    @property
+    def faces(self):
+        return self.mano.faces
+
+
+class _Args(dict):
+    __getattr__ = dict.get
+
+
+DEFAULT_ARGS = _Args(backbone="resnet50", pos_enc="center+corner_latent", n_freq_pos_enc=4,
+                     use_glb_feat=True, separate_hands=False, tf_decoder=False, use_grasp_loss=True,
+                     use_glb_feat_w_grasp=True, no_crops=False, use_depth_loss=False,
+                     regress_center_corner=False, use_render_seg_loss=False, img_res=224,
+                     focal_length=1000.0)
+
+
+# --------------------------------------------------------------------------------------------------
+class HandsLight(nn.Module):
+    def __init__(self, backbone="resnet50", focal_length=1000.0, img_res=224, args=None,
+                 mano_assets=None):
+        super().__init__()
+        args = args if args is not None else DEFAULT_ARGS
+        get = (lambda k, d=None: args.get(k, d)) if hasattr(args, "get") else (lambda k, d=None: getattr(args, k, d))
+        self.args = args
+        if backbone != "resnet50":
+            raise NotImplementedError("hands_amd.HandsLight: only backbone='resnet50' is built")
+        unsupported = {
+            "pos_enc": get("pos_enc") != "center+corner_latent",
+            "separate_hands": bool(get("separate_hands", False)),
+            "tf_decoder": bool(get("tf_decoder", False)),
+            "no_crops": bool(get("no_crops", False)),
+            "use_depth_loss": bool(get("use_depth_loss", False)),
+            "regress_center_corner": bool(get("regress_center_corner", False)),
+            "use_render_seg_loss": bool(get("use_render_seg_loss", False)),
+            "use_glb_feat=False": not get("use_glb_feat", False),
+            "use_grasp_loss=False": not get("use_grasp_loss", False),
+            "use_glb_feat_w_grasp=False": not get("use_glb_feat_w_grasp", False),
+        }
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f"hands_amd.HandsLight: unsupported config switches {bad}")
+        self.n_freq = int(get("n_freq_pos_enc", 4))
+        feat_dim = 2048
+        self.feat_dim = feat_dim
+        self.backbone = ResNet50Params()
+        self.hand_backbone = ResNet50Params()
+        self.head_r = HandHMR(feat_dim, True, 3)
+        self.head_l = HandHMR(feat_dim, False, 3)
+        fc_dim = feat_dim + 5 * 4 * self.n_freq
+        self.feature_conv = nn.Sequential(
+            nn.Conv2d(fc_dim, 1024, 1, bias=False), nn.ReLU(inplace=True),
+            nn.Conv2d(1024, 512, 3, bias=False), nn.ReLU(inplace=True),
+            nn.Conv2d(512, 256, 3, bias=False), nn.ReLU(inplace=True),
+            nn.Flatten(), nn.Linear(256 * 3 * 3, feat_dim), nn.ReLU(inplace=True))
+        assets = mano_assets or (None, None)
+        self.mano_r = MANOHead(True, focal_length, img_res, assets[0])
+        self.mano_l = MANOHead(False, focal_length, img_res, assets[1])
+        self.grasp_classifier = nn.Sequential(
+            nn.Linear(10 + 144 + feat_dim, 1024), nn.ReLU(inplace=True), nn.Linear(1024, 512),
+            nn.ReLU(inplace=True), nn.Linear(512, 128), nn.ReLU(inplace=True), nn.Linear(128, 9))
+        self.mode = "train"
+        self.img_res = img_res
+        self.focal_length = focal_length
+        self._packed = None
+        self._packed_dev = None
+        self._ws = {}
+        self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_packed())
+
+    # ---- packing ------------------------------------------------------------------------------
+    def invalidate_packed(self):
+        self._packed = None
+        self._ws = {}
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate_packed()
+        return super()._apply(fn, *a, **k)
+
+    @torch.no_grad()
+    def _pack_trunk(self, net: ResNet50Params, dev):
+        cpu = lambda t: t.detach().cpu()
+        bnp = lambda bn: (cpu(bn.weight), cpu(bn.bias), cpu(bn.running_mean), cpu(bn.running_var))
+        P = {}
+        w, b = fold_bn(cpu(net.conv1.weight), *bnp(net.bn1))
+        P["stem"] = pack_conv(w, b, 2, 3, dev, cin_pad_to=4)
+        blocks = []
+        for li in range(1, 5):
+            for blk in getattr(net, f"layer{li}"):
+                e = {}
+                w, b = fold_bn(cpu(blk.conv1.weight), *bnp(blk.bn1)); e["c1"] = pack_conv(w, b, 1, 0, dev)
+                w, b = fold_bn(cpu(blk.conv2.weight), *bnp(blk.bn2)); e["c2"] = pack_conv(w, b, blk.stride, 1, dev)
+                w, b = fold_bn(cpu(blk.conv3.weight), *bnp(blk.bn3)); e["c3"] = pack_conv(w, b, 1, 0, dev)
+                if blk.downsample is not None:
+                    w, b = fold_bn(cpu(blk.downsample[0].weight), *bnp(blk.downsample[1]))
+                    e["ds"] = pack_conv(w, b, blk.stride, 0, dev)
+                blocks.append(e)
+        P["blocks"] = blocks
+        return P
+
+    @torch.no_grad()
+    def _pack_head(self, head: HandHMR, dev):
+        cpu = lambda t: t.detach().cpu()
+        F = self.feat_dim
+        P = {}
+        ci = head.cam_init
+        P["ci0"] = pack_linear(cpu(ci[0].weight), cpu(ci[0].bias), dev)
+        P["ci2"] = pack_linear(cpu(ci[2].weight), cpu(ci[2].bias), dev)
+        P["ci4"] = pack_linear(cpu(ci[4].weight), cpu(ci[4].bias), dev, n_total=4)
+        rf = head.hmr_layer.refine
+        P["r0"] = pack_linear(cpu(rf[0].weight), cpu(rf[0].bias), dev, col_index=hmr_state_columns(F),
+                              k_total=F + HMR_VEC)
+        P["r3"] = pack_linear(cpu(rf[3].weight), cpu(rf[3].bias), dev)
+        d = head.hmr_layer.decoders
+        wd = torch.cat([cpu(d["pose_6d"].weight), cpu(d["shape"].weight), cpu(d["cam_t/wp"].weight)], 0)
+        bd = torch.cat([cpu(d["pose_6d"].bias), cpu(d["shape"].bias), cpu(d["cam_t/wp"].bias)], 0)
+        rows = list(range(96)) + [96 + i for i in range(10)] + [108 + i for i in range(3)]
+        P["dec"] = pack_linear(wd, bd, dev, row_index=rows, n_total=HMR_VEC)
+        return P
+
+    @torch.no_grad()
+    def _pack(self, dev):
+        cpu = lambda t: t.detach().cpu()
+        F = self.feat_dim
+        P = {"backbone": self._pack_trunk(self.backbone, dev),
+             "hand_backbone": self._pack_trunk(self.hand_backbone, dev),
+             "head_r": self._pack_head(self.head_r, dev), "head_l": self._pack_head(self.head_l, dev)}
+        fc = self.feature_conv
+        P["fc0"] = pack_conv(cpu(fc[0].weight), None, 1, 0, dev)
+        P["fc2"] = pack_conv(cpu(fc[2].weight), None, 1, 0, dev)
+        P["fc4"] = pack_conv(cpu(fc[4].weight), None, 1, 0, dev)
+        # nn.Flatten on NCHW (B,256,3,3): reference column c*9 + hw; NHWC buffer column hw*256 + c
+        col = [(k % 9) * 256 + (k // 9) for k in range(256 * 9)]
+        P["fc7"] = pack_linear(cpu(fc[7].weight), cpu(fc[7].bias), dev, col_index=col)
+        g = self.grasp_classifier
+        # reference cat([shape 10, rot 144, feat_vec F]) -> packed row [feat_vec F | rot 144 | shape 10]
+        gcol = [F + 144 + i for i in range(10)] + [F + i for i in range(144)] + list(range(F))
+        P["g0"] = pack_linear(cpu(g[0].weight), cpu(g[0].bias), dev, col_index=gcol, k_total=F + 154)
+        P["g2"] = pack_linear(cpu(g[2].weight), cpu(g[2].bias), dev)
+        P["g4"] = pack_linear(cpu(g[4].weight), cpu(g[4].bias), dev)
+        P["g6"] = pack_linear(cpu(g[6].weight), cpu(g[6].bias), dev, n_total=12)
+        P["mano_r"] = pack_mano(self.mano_r.mano.asset(), dev)
+        P["mano_l"] = pack_mano(self.mano_l.mano.asset(), dev)
+        for side in ("mano_r", "mano_l"):
+            m = P[side]
+            m["consts"] = ManoConsts(ptr(m["pose_mean"]), ptr(m["J_template"]), ptr(m["J_shapedirs"]),
+                                     ptr(m["lbs_weights"]), ptr(m["tip_ids"]))
+        return P
+
+    def packed(self, dev):
+        if self._packed is None or self._packed_dev != dev:
+            self._packed = self._pack(dev)
+            self._packed_dev = dev
+        return self._packed
+
+    # ---- buffers ------------------------------------------------------------------------------
+    def _buf(self, name, numel, dev):
+        t = self._ws.get(name)
+        if t is None or t.numel() < numel or t.device != dev:
+            t = torch.empty(numel, dtype=torch.float32, device=dev)
+            self._ws[name] = t
+        return t
+
+    # ---- kernel launch helpers ----------------------------------------------------------------
+    @staticmethod
+    def _conv(L, pc: PackedConv, x, B, H, W, out, relu, stream, res=None, in_ps=None, out_ps=None,
+              res_ps=None, x_off=0, out_off=0, res_off=0):
+        Ho = (H + 2 * pc.pad - pc.KH) // pc.stride + 1
+        Wo = (W + 2 * pc.pad - pc.KW) // pc.stride + 1
+        d = ConvDesc(B, H, W, pc.Cin, Ho, Wo, pc.Cout, pc.KH, pc.KW, pc.stride, pc.pad,
+                     in_ps or pc.Cin, out_ps or pc.Cout, (res_ps or pc.Cout) if res is not None else 0,
+                     pc.Kpad, 1 if relu else 0)
+        check(L.hands_conv2d_nhwc_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
+                                      ptr(res, res_off) if res is not None else None, ptr(out, out_off),
+                                      stream), "hands_conv2d_nhwc_f32")
+        return Ho, Wo
+
+    def _trunk(self, L, P, x4, B, res_in, stream, tag, cap_B):
+        """ResNet-50 trunk on an NHWC4 batch; returns (B,7,7,2048) features (flat tensor)."""
+        dev = x4.device
+        H = W = res_in
+        per = 112 * 112 * 64 * (res_in * res_in) // (224 * 224) + 64
+        cap = cap_B * per
+        a = self._buf("trunk_a", cap, dev); b = self._buf("trunk_b", cap, dev)
+        t1 = self._buf("trunk_t1", cap, dev); t2 = self._buf("trunk_t2", cap, dev)
+        ds = self._buf("trunk_ds", cap, dev)
+        Ho, Wo = self._conv(L, P["stem"], x4, B, H, W, a, True, stream)
+        check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(b), B, Ho, Wo, 64, stream), "maxpool")
+        H, W = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+        cur, nxt = b, a
+        nblk = len(P["blocks"])
+        for i, e in enumerate(P["blocks"]):
+            self._conv(L, e["c1"], cur, B, H, W, t1, True, stream)
+            H2, W2 = self._conv(L, e["c2"], t1, B, H, W, t2, True, stream)
+            if "ds" in e:
+                self._conv(L, e["ds"], cur, B, H, W, ds, False, stream)
+                ident = ds
+            else:
+                ident = cur
+            dst = nxt if i + 1 < nblk else self._buf("feat_" + tag, B * H2 * W2 * e["c3"].Cout, dev)
+            self._conv(L, e["c3"], t2, B, H2, W2, dst, True, stream, res=ident)
+            H, W = H2, W2
+            cur, nxt = dst, cur
+            if i + 1 == nblk:
+                return dst, H, W
+        raise AssertionError
+
+    # ---- forward ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, inputs, meta_info):
+        L = _lib.lib()
+        img = inputs["img"]
+        dev = img.device
+        if dev.type != "cuda":
+            raise RuntimeError("hands_amd.HandsLight runs on a HIP device only (no CPU fallback); "
+                               "move the module and its inputs to 'cuda'")
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+        img, r_img, l_img = f32(img), f32(inputs["r_img"]), f32(inputs["l_img"])
+        K = f32(meta_info["intrinsics"])
+        assert K.shape[1:] == (3, 3)                               # transforms.py:322-326
+        bz, c, res, res_w = img.shape
+        assert c == 3 and res == res_w and r_img.shape == img.shape and l_img.shape == img.shape
+        B2 = 2 * bz
+        F = self.feat_dim
+        P = self.packed(dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        buf = lambda n, numel: self._buf(n, numel, dev)
+
+        # -- trunks (model.py:193, 238-239); r and l crops share weights -> one 2*bz batch -------
+        x4 = buf("x4", B2 * res * res * 4)
+        check(L.hands_nchw3_to_nhwc4_f32(ptr(img), ptr(x4), bz, res, res, stream), "nchw->nhwc4")
+        featg, fh, fw = self._trunk(L, P["backbone"], x4, bz, res, stream, "g", B2)
+        check(L.hands_nchw3_to_nhwc4_f32(ptr(r_img), ptr(x4), bz, res, res, stream), "nchw->nhwc4")
+        check(L.hands_nchw3_to_nhwc4_f32(ptr(l_img), ptr(x4, bz * res * res * 4), bz, res, res, stream),
+              "nchw->nhwc4")
+        feath, fh, fw = self._trunk(L, P["hand_backbone"], x4, B2, res, stream, "h", B2)
+        HW = fh * fw
+
+        # -- sum-pool (model.py:196) and KPE concat (model.py:258-271) ---------------------------
+        feat_vec = buf("feat_vec", bz * F)
+        check(L.hands_sumpool_nhwc_f32(ptr(featg), ptr(feat_vec), bz, HW, F, F, stream), "sumpool")
+        center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
+        corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0)
+        Cc = F + 20 * self.n_freq
+        cat = buf("cat", B2 * HW * Cc)
+        check(L.hands_kpe_concat_f32(ptr(feath), ptr(featg), ptr(center), ptr(corner), ptr(cat), B2, bz,
+                                     HW, F, self.n_freq, stream), "kpe_concat")
+
+        # -- feature_conv (model.py:91-101, 313-314) -> HMR state rows ---------------------------
+        f1 = buf("fc1", B2 * HW * 1024)
+        self._conv(L, P["fc0"], cat, B2, fh, fw, f1, True, stream)
+        f2 = buf("fc2", B2 * (fh - 2) * (fw - 2) * 512)
+        h2, w2 = self._conv(L, P["fc2"], f1, B2, fh, fw, f2, True, stream)
+        f3 = buf("fc3", B2 * (h2 - 2) * (w2 - 2) * 256)
+        h3, w3 = self._conv(L, P["fc4"], f2, B2, h2, w2, f3, True, stream)
+        assert h3 * w3 * 256 == P["fc7"].Cin
+        ld = F + HMR_VEC
+        state = buf("state", B2 * ld)
+        self._conv(L, P["fc7"], f3, B2, 1, 1, state, True, stream, out_ps=ld)
+
+        # -- HandHMR x2 (hand_hmr.py:73-92, hmr_layer.py:67-86) ----------------------------------
+        h512a, h512b = buf("h512a", bz * 512), buf("h512b", bz * 512)
+        x1, x2 = buf("x1024a", bz * 1024), buf("x1024b", bz * 1024)
+        caminit4 = buf("caminit4", B2 * 4)
+        for side, hp in ((0, P["head_r"]), (1, P["head_l"])):
+            so = side * bz * ld
+            self._conv(L, hp["ci0"], state, bz, 1, 1, h512a, True, stream, in_ps=ld, x_off=so)
+            self._conv(L, hp["ci2"], h512a, bz, 1, 1, h512b, True, stream)
+            self._conv(L, hp["ci4"], h512b, bz, 1, 1, caminit4, False, stream, out_off=side * bz * 4)
+            check(L.hands_hmr_init_f32(ptr(state, so), ptr(caminit4, side * bz * 4), bz, ld, F, stream),
+                  "hmr_init")
+            for _ in range(3):
+                self._conv(L, hp["r0"], state, bz, 1, 1, x1, True, stream, in_ps=ld, x_off=so)
+                self._conv(L, hp["r3"], x1, bz, 1, 1, x2, True, stream)
+                self._conv(L, hp["dec"], x2, bz, 1, 1, state, False, stream, res=state, out_ps=ld,
+                           res_ps=ld, out_off=so + F, res_off=so + F)
+        rotmat = buf("rotmat", B2 * 144)
+        check(L.hands_rot6d_to_matrix_f32(ptr(state, F), ld, ptr(rotmat), B2, stream), "rot6d")
+        st = state[: B2 * ld].view(B2, ld)
+        shape = st[:, F + 96:F + 106].contiguous()
+        cam = st[:, F + 108:F + 111].contiguous()
+        caminit = caminit4[: B2 * 4].view(B2, 4)[:, :3].contiguous()
+
+        # -- is_flipped swap (model.py:341-368), per sample on device ----------------------------
+        flipped = meta_info["is_flipped"].to(device=dev, dtype=torch.int64).contiguous()
+        rot_m = torch.empty(B2, 16, 3, 3, device=dev)
+        shape_m = torch.empty(B2, 10, device=dev)
+        cam_m = torch.empty(B2, 3, device=dev)
+        caminit_m = torch.empty(B2, 3, device=dev)
+        check(L.hands_flip_swap_f32(ptr(flipped), ptr(rotmat), ptr(shape), ptr(cam), ptr(caminit),
+                                    ptr(rot_m), ptr(shape_m), ptr(cam_m), ptr(caminit_m), bz, stream),
+              "flip_swap")
+
+        # -- MANOHead x2 (mano_head.py:21-65) -----------------------------------------------------
+        blend_in = buf("blend_in", bz * 160)
+        Abuf, j16 = buf("mano_A", bz * 192), buf("mano_j16", bz * 48)
+        vposed = buf("vposed", bz * 2336)
+        output = xdict()
+        for side, (mp, post) in enumerate(((P["mano_r"], ".r"), (P["mano_l"], ".l"))):
+            ro = side * bz
+            check(L.hands_mano_pose_f32(C.byref(mp["consts"]), ptr(rot_m, ro * 144), ptr(shape_m, ro * 10), 10,
+                                        ptr(blend_in), 160, ptr(Abuf), ptr(j16), bz, stream), "mano_pose")
+            self._conv(L, mp["blend"], blend_in, bz, 1, 1, vposed, False, stream)
+            o = {"vertices": torch.empty(bz, 778, 3, device=dev), "joints3d": torch.empty(bz, 21, 3, device=dev),
+                 "v3d.cam": torch.empty(bz, 778, 3, device=dev), "j3d.cam": torch.empty(bz, 21, 3, device=dev),
+                 "j2d.norm": torch.empty(bz, 21, 2, device=dev), "cam_t": torch.empty(bz, 3, device=dev)}
+            mo = ManoOut(ptr(o["vertices"]), ptr(o["joints3d"]), ptr(o["v3d.cam"]), ptr(o["j3d.cam"]),
+                         ptr(o["j2d.norm"]), ptr(o["cam_t"]))
+            check(L.hands_mano_skin_f32(C.byref(mp["consts"]), ptr(vposed), 2336, ptr(Abuf), ptr(j16),
+                                        ptr(cam_m, ro * 3), ptr(K), float(self.img_res), 0.1, C.byref(mo),
+                                        bz, stream), "mano_skin")
+            md = xdict()                                           # key order of mano_head.py:53-61
+            md["cam_t.wp"] = cam_m[ro:ro + bz]
+            md["cam_t"] = o["cam_t"]
+            md["joints3d"] = o["joints3d"]
+            md["vertices"] = o["vertices"]
+            md["j3d.cam"] = o["j3d.cam"]
+            md["v3d.cam"] = o["v3d.cam"]
+            md["j2d.norm"] = o["j2d.norm"]
+            md["beta"] = shape_m[ro:ro + bz]
+            md["pose"] = rot_m[ro:ro + bz]
+            md = md.postfix(post)
+            md["cam_t.wp.init" + post] = caminit_m[ro:ro + bz]      # model.py:392-393
+            output.merge(prefix_dict(md, "mano."))                  # model.py:395-399
+
+        # -- grasp classifier on the UN-flipped HMR outputs (model.py:401-411) -------------------
+        gld = P["g0"].Cin
+        gin = buf("grasp_in", B2 * gld)
+        check(L.hands_grasp_input_f32(ptr(state, F + 96), ld, ptr(rotmat), ptr(feat_vec), ptr(gin), B2, bz,
+                                      F, gld, stream), "grasp_input")
+        g1, g2, g3 = buf("g1", B2 * 1024), buf("g2", B2 * 512), buf("g3", B2 * 128)
+        g4 = torch.empty(B2, 12, device=dev)
+        self._conv(L, P["g0"], gin, B2, 1, 1, g1, True, stream)
+        self._conv(L, P["g2"], g1, B2, 1, 1, g2, True, stream)
+        self._conv(L, P["g4"], g2, B2, 1, 1, g3, True, stream)
+        self._conv(L, P["g6"], g3, B2, 1, 1, g4, False, stream)
+        grasp = xdict()
+        grasp["grasp.r"] = g4[:bz, :9].contiguous()
+        grasp["grasp.l"] = g4[bz:, :9].contiguous()
+        output.merge(grasp)
+        return output

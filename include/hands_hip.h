@@ -1,0 +1,156 @@
+/*
+ * hands_hip.h -- C ABI of libhands_hip.so: the MI355X (gfx950) forward path of the WildHands
+ * hand-mesh regressor (hands_light), hand-written HIP.
+ *
+ * The reference (ap229997/hands) is 100 % Python and has no FFI: the boundary of its hot path is
+ * `HandsLight.forward(inputs, meta_info)` (src/models/hands_light/model.py:187-437).  Every entry
+ * point below replaces the ATen ops that one statement of that function dispatches; the statement
+ * is cited per function.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers to fp32 unless stated.  The caller owns every buffer; the
+ *     library never allocates, frees or synchronises.  Work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream).
+ *   - Activations are NHWC ("pixel-major"): element (b,h,w,c) at ((b*H+h)*W+w)*pix_stride + c.
+ *   - Return value: 0 on success, otherwise a hipError_t (or HANDS_EINVAL for a bad descriptor);
+ *     hands_error_string() gives text.  No global mutable state; re-entrant across streams.
+ */
+#ifndef HANDS_HIP_H
+#define HANDS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HANDS_EINVAL 10001
+#define HANDS_ABI_VERSION 1
+
+typedef void* hands_stream_t;
+
+int hands_abi_version(void);
+const char* hands_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution / linear layer as implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *   out[m, n] = act( bias[n] + sum_k patch(m, k) * w[n, k]  (+ residual[m, n]) )
+ *   m = (b, ho, wo) flattened, k = (kh, kw, cin) flattened, act = ReLU if relu != 0.
+ * Replaces nn.Conv2d + eval-mode BatchNorm2d (folded into w/bias by the host) + ReLU + the
+ * bottleneck's residual add: src/nets/backbone/resnet.py:134-154,264-280; feature_conv
+ * model.py:91-101; and every nn.Linear of the heads (H=W=KH=KW=1): hand_hmr.py:34-40,
+ * hmr_layer.py:47-62, model.py:117-125.
+ *
+ * Weight layout (produced once by hands_amd.packing): [Cout_pad][Kpad] row-major, k ordered
+ * (kh, kw, cin), Kpad = round_up(KH*KW*Cin, 16) zero-filled, Cout_pad = round_up(Cout, 128)
+ * zero-filled.  bias has Cout_pad entries.  Cin % 4 == 0 and Cout % 4 == 0 are required;
+ * Cin % 16 == 0 unless Cin == 4 (the RGB0 stem).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct hands_conv_desc {
+  int32_t B, H, W, Cin;      /* input  (B,H,W,Cin) */
+  int32_t Ho, Wo, Cout;      /* output (B,Ho,Wo,Cout) */
+  int32_t KH, KW, stride, pad;
+  int32_t in_pix_stride;     /* floats between consecutive input pixels  (>= Cin)  */
+  int32_t out_pix_stride;    /* floats between consecutive output pixels (>= Cout) */
+  int32_t res_pix_stride;    /* floats between consecutive residual pixels; ignored if residual==NULL */
+  int32_t Kpad;              /* packed weight row length */
+  int32_t relu;
+} hands_conv_desc;
+
+int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
+                          const float* bias, const float* residual, float* out,
+                          hands_stream_t stream);
+
+/* NCHW (B,3,H,W) image batch -> NHWC with C padded to 4 (4th channel = 0).
+ * Replaces the implicit layout of inputs["img"|"r_img"|"l_img"] (model.py:188,238-239). */
+int hands_nchw3_to_nhwc4_f32(const float* in, float* out, int B, int H, int W, hands_stream_t stream);
+
+/* MaxPool2d(kernel 3, stride 2, padding 1) on NHWC.  resnet.py:268. C % 4 == 0. */
+int hands_maxpool3x3s2_nhwc_f32(const float* in, float* out, int B, int H, int W, int C,
+                                hands_stream_t stream);
+
+/* feat_vec[b, c] = sum_p feat[b, p, c]  (a SUM over the 7x7 map, not a mean).  model.py:196. */
+int hands_sumpool_nhwc_f32(const float* feat, float* out, int B, int HW, int C, int out_stride,
+                           hands_stream_t stream);
+
+/* out[b2, p, :] = cat(crop[b2,p,:] + glb[b2 % Bg, p, :], center_enc(b2), corner_enc(b2)).
+ * crop holds the right-hand samples then the left-hand samples (2*Bg rows); encodings are the
+ * reference's [sin(2^k a), cos(2^k a)] laid out (L, c, 2).  model.py:258-271, 444-460.
+ * center_angle (2*Bg, 2), corner_angle (2*Bg, 8); out channels = C + 4*L + 16*L. */
+int hands_kpe_concat_f32(const float* crop, const float* glb, const float* center_angle,
+                         const float* corner_angle, float* out, int B2, int Bg, int HW, int C,
+                         int n_freq, hands_stream_t stream);
+
+/* HMR state rows (ld = F + 112, every segment 16-byte aligned):
+ *   [feat F | pose6d 96 | shape 10 | 0 0 | cam 3 | 0]
+ * Writes the identity-6D / zero-shape initial vectors (hand_hmr.py:46-56) and copies the cam_init
+ * MLP output (rows of 4 floats: s, tx, ty, pad) into columns F..F+111 of every row. */
+int hands_hmr_init_f32(float* state, const float* cam_init, int B, int ld, int F,
+                       hands_stream_t stream);
+
+/* rotation_6d_to_matrix (pytorch3d; call site hand_hmr.py:85-87): Gram-Schmidt, rows.
+ * pose6d rows have stride ld6; rotmat is (B,16,3,3) contiguous. */
+int hands_rot6d_to_matrix_f32(const float* pose6d, int ld6, float* rotmat, int B,
+                              hands_stream_t stream);
+
+/* is_flipped branch of HandsLight.forward (model.py:341-368): per-sample swap of the two hands'
+ * predictions with mirrored axis-angle (y,z negated) and cam ty sign flip.  Arrays hold the right
+ * hand in rows [0,Bg) and the left hand in rows [Bg,2Bg).  is_flipped: int64 (Bg).
+ * In/out: rotmat (2Bg,16,3,3), shape (2Bg,10), cam (2Bg,3), cam_init (2Bg,3) -> *_out. */
+int hands_flip_swap_f32(const int64_t* is_flipped, const float* rotmat, const float* shape,
+                        const float* cam, const float* cam_init, float* rotmat_out,
+                        float* shape_out, float* cam_out, float* cam_init_out, int Bg,
+                        hands_stream_t stream);
+
+/* grasp-head input rows [feat_vec(F) | rotmat(144) | shape(10) | 0-pad]: the reference's
+ * cat([shape, pose.view(bz,-1), feat_vec]) (model.py:401-404) with the columns permuted so the
+ * segments are 16-byte aligned; the packed grasp_classifier.0 weight uses the same permutation.
+ * Rows [0,Bg) are the right hand, [Bg,2Bg) the left; feat_vec (Bg,F) is shared by both. */
+int hands_grasp_input_f32(const float* shape, int ld_shape, const float* rotmat,
+                          const float* feat_vec, float* out, int B2, int Bg, int F, int ld_out,
+                          hands_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * MANO layer (MANOHead.forward, src/nets/hand_heads/mano_head.py:21-65 -> common/rot.py:118-193,
+ * smplx.MANO / smplx.lbs, common/camera.py:456-474, common/transforms.py:316-329,
+ * common/data_utils.py:361-365).  Three launches per hand side:
+ *   1. hands_mano_pose_f32     rotmat -> axis-angle -> (+pose_mean) -> Rodrigues -> pose feature;
+ *                              joints J(beta); forward kinematics -> skinning transforms A (B,16,12)
+ *                              and posed joints (B,16,3); writes the blend-GEMM input rows
+ *                              [beta(10) | pose_feature(135) | 0-pad] (B, ld_blend).
+ *   2. hands_conv2d_nhwc_f32   v_posed = v_template + [beta|pf] @ [shapedirs; posedirs]
+ *                              (the 778x3 x 145 contraction on MFMA), output (B, ld_vp).
+ *   3. hands_mano_skin_f32     per-vertex blend of A, apply, fingertip joints, weak-perspective
+ *                              camera, K-projection, 2x/res-1 normalisation.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct hands_mano_consts {
+  const float* pose_mean;   /* (48)      zeros(3) ++ hands_mean(45) */
+  const float* J_template;  /* (16,3)    J_regressor @ v_template */
+  const float* J_shapedirs; /* (48,10)   J_regressor @ shapedirs */
+  const float* lbs_weights; /* (778,16) */
+  const int32_t* tip_ids;   /* (5) */
+} hands_mano_consts;
+
+int hands_mano_pose_f32(const hands_mano_consts* c, const float* rotmat, const float* betas,
+                        int ld_betas, float* blend_in, int ld_blend, float* A, float* joints16,
+                        int B, hands_stream_t stream);
+
+typedef struct hands_mano_out {
+  float* vertices;  /* (B,778,3) */
+  float* joints3d;  /* (B,21,3)  */
+  float* v3d_cam;   /* (B,778,3) */
+  float* j3d_cam;   /* (B,21,3)  */
+  float* j2d_norm;  /* (B,21,2)  */
+  float* cam_t;     /* (B,3)     */
+} hands_mano_out;
+
+int hands_mano_skin_f32(const hands_mano_consts* c, const float* v_posed, int ld_vp,
+                        const float* A, const float* joints16, const float* cam_wp,
+                        const float* K, float img_res, float min_s, const hands_mano_out* out,
+                        int B, hands_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HANDS_HIP_H */

@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a HIP device (run on the MI355X box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def recipe_model():
+    """hands_amd.HandsLight with the deterministic weight recipe (CPU parameters)."""
+    import hands_amd
+    m = hands_amd.HandsLight()
+    hands_amd.apply_recipe(m)
+    m.eval()
+    return m
+
+
+@pytest.fixture(scope="session")
+def recipe_sd(recipe_model):
+    return {k: v.detach().clone() for k, v in recipe_model.state_dict().items()}
