@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- hands/sec of the hands_light forward path (BASELINE.json config 2) on N MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--bz 256]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one HandsLight.forward over bz=256 synthetic samples per GPU (1 global image + right crop
++ left crop each = 2 hands; 768 ResNet-50 trunk passes) followed, when N > 1, by one RCCL
+all-gather of the packed predictions.  Inputs are resident in HBM before the timed region; outputs
+stay on the device.  Weak scaling: per-GPU work is fixed, value = N * 2 * bz * K / t.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (conv_igemm_f32, every
+convolution / linear layer of the path): achieved = algorithmic FLOPs of all its launches in one
+step / the summed duration of those launches, each bracketed by HIP events on the launch stream in
+a separate instrumented step.  `cpu_baseline` times the CPU oracle (a torch-CPU port of the
+reference path) on the box's host cores on a bounded sample and doubles as the MPJPE checker.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+def host_cores():
+    """Cores this process may really use: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bz", type=int, default=256, help="samples per GPU per step (2 hands each)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-bz", type=int, default=16)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import hands_amd
+    from hands_amd.dist import gather_predictions
+    from hands_amd.hands_light import HandsLight
+
+    model = hands_amd.apply_recipe(hands_amd.HandsLight())
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    model = model.to(dev).eval()
+    bz = args.bz
+    inputs, meta = hands_amd.synthetic_inputs(bz, seed=rank, device=dev)
+
+    def step():
+        out = model(inputs, meta)
+        return gather_predictions(out) if world > 1 else out
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    n_gpus = world
+    ms_per_step = elapsed / args.steps * 1e3
+    hands_per_s = n_gpus * 2 * bz * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: instrumented step, HIP events around every launch ----
+    events = []
+    macs = [0]
+
+    def hook(phase, pc, npix):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(dev))   # the stream the C ABI launches on
+        events.append(ev)
+        if phase == "begin":
+            macs[0] += pc.macs_per_pixel * npix
+
+    n_prof = 3
+    HandsLight.conv_hook = staticmethod(hook)
+    for _ in range(n_prof):
+        model(inputs, meta)
+    torch.cuda.synchronize(dev)
+    HandsLight.conv_hook = None
+    durs_ms = [events[i].elapsed_time(events[i + 1]) for i in range(0, len(events), 2)]
+    launches = len(durs_ms) // n_prof
+    conv_ms = sum(durs_ms) / n_prof
+    conv_flops = 2.0 * macs[0] / n_prof
+    achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "conv_igemm_f32_kernel", "achieved": round(achieved, 2),
+                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": None, "launches_per_step": launches,
+                "avg_launch_us": round(conv_ms * 1e3 / launches, 2),
+                "kernel_ms_per_step": round(conv_ms, 3),
+                "algorithmic_gflop_per_sample": round(conv_flops / bz / 1e9, 3)}
+
+    # ---- CPU baseline (oracle = torch-CPU port of the reference path) + MPJPE checker ----------
+    cpu_baseline = None
+    parity = None
+    if not args.no_cpu_baseline:
+        from oracle import hands_oracle as O
+        ci, cm = hands_amd.synthetic_inputs(args.cpu_bz, seed=0)
+        cb = args.cpu_bz
+        ar, al = hands_amd.synthetic_mano_asset(True), hands_amd.synthetic_mano_asset(False)
+        cores = host_cores()
+        best = None
+        ref = None
+        for nthreads in sorted({max(1, cores // 2), cores}):
+            torch.set_num_threads(nthreads)
+            ref = O.hands_light_forward(sd_cpu, ar, al, ci, cm)      # warm-up + checker output
+            times = []
+            t_budget = time.perf_counter()
+            while len(times) < 5 and (time.perf_counter() - t_budget) < 12.0:
+                t1 = time.perf_counter()
+                O.hands_light_forward(sd_cpu, ar, al, ci, cm)
+                times.append(time.perf_counter() - t1)
+            med = sorted(times)[len(times) // 2]
+            if best is None or med < best[0]:
+                best = (med, nthreads, len(times))
+        med, nthreads, nruns = best
+        cpu_baseline = {"value": round(2 * cb / med, 2), "unit": "hands/s", "cores": nthreads, "kind": "port",
+                        "sample": f"oracle (torch-CPU port of the reference path) hands_light forward, bz={cb} "
+                        f"({2 * cb} hands), median of {nruns} runs, fp32; host allows {cores} cores "
+                        f"(cgroup quota / affinity), best of {{cores/2, cores}} threads"}
+        got = model({k: v.to(dev) for k, v in ci.items()}, {k: v.to(dev) for k, v in cm.items()})
+        verr = max((got[f"mano.vertices.{h}"].cpu() - ref[f"mano.vertices.{h}"]).abs().max().item() for h in "rl")
+        mp = max(O.mpjpe_ra_mm(got[f"mano.joints3d.{h}"].cpu(), ref[f"mano.joints3d.{h}"]) for h in "rl")
+        parity = {"mpjpe_vs_ref_mm": round(mp, 7), "max_vertex_err_m": float(f"{verr:.3e}"), "checked_hands": 2 * cb}
+
+    line = {
+        "metric": "hands_per_sec", "value": round(hands_per_s, 1), "unit": "hands/s", "n_gpus": n_gpus,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "hands_light ResNet-50 x3 + feature_conv + HMR + MANO, 224x224, "
+                               f"bz={bz} samples/GPU ({2 * bz} hands, {3 * bz} trunk passes)",
+                   "per_gpu_batch": bz, "global_batch": bz * n_gpus, "img_res": 224,
+                   "parallelism": f"dp{n_gpus}" + ("+allgather" if n_gpus > 1 else "")},
+        "hands_per_sec_per_gpu": round(hands_per_s / n_gpus, 1),
+        "path_tflops": round(hands_per_s * 12.77e9 / 1e12 / n_gpus, 2),
+        "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+    }
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -113,7 +113,12 @@ class MANOHead(nn.Module):
 
 
 class _Args(dict):
-    __getattr__ = dict.get
+    """attribute *and* ``.get`` access, like the reference's EasyDict args (parser.py:39-58)."""
+
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return self.get(k)
 
 
 DEFAULT_ARGS = _Args(backbone="resnet50", pos_enc="center+corner_latent", n_freq_pos_enc=4,
@@ -269,6 +274,8 @@ class HandsLight(nn.Module):
         return t
 
     # ---- kernel launch helpers ----------------------------------------------------------------
+    conv_hook = None   # bench.py installs a callback here to bracket every GEMM launch with events
+
     @staticmethod
     def _conv(L, pc: PackedConv, x, B, H, W, out, relu, stream, res=None, in_ps=None, out_ps=None,
               res_ps=None, x_off=0, out_off=0, res_off=0):
@@ -277,9 +284,14 @@ class HandsLight(nn.Module):
         d = ConvDesc(B, H, W, pc.Cin, Ho, Wo, pc.Cout, pc.KH, pc.KW, pc.stride, pc.pad,
                      in_ps or pc.Cin, out_ps or pc.Cout, (res_ps or pc.Cout) if res is not None else 0,
                      pc.Kpad, 1 if relu else 0)
+        hook = HandsLight.conv_hook
+        if hook is not None:
+            hook("begin", pc, B * Ho * Wo)
         check(L.hands_conv2d_nhwc_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
                                       ptr(res, res_off) if res is not None else None, ptr(out, out_off),
                                       stream), "hands_conv2d_nhwc_f32")
+        if hook is not None:
+            hook("end", pc, B * Ho * Wo)
         return Ho, Wo
 
     def _trunk(self, L, P, x4, B, res_in, stream, tag, cap_B):

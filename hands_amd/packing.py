@@ -35,6 +35,7 @@ class PackedConv:
     stride: int
     pad: int
     Kpad: int
+    macs_per_pixel: int = 0   # ALGORITHMIC multiply-accumulates per output pixel (true, unpadded dims)
 
 
 def fold_bn(w, bn_w, bn_b, bn_mean, bn_var, eps=BN_EPS):
@@ -60,7 +61,8 @@ def pack_conv(w, bias, stride, pad, device, cin_pad_to=None) -> PackedConv:
     bp = torch.zeros(Cout_pad, dtype=torch.float32)
     if bias is not None:
         bp[:Cout] = bias.float()
-    return PackedConv(wp.to(device), bp.to(device), Cin_p, Cout_s, KH, KW, stride, pad, Kpad)
+    return PackedConv(wp.to(device), bp.to(device), Cin_p, Cout_s, KH, KW, stride, pad, Kpad,
+                      macs_per_pixel=Cout * Cin * KH * KW)
 
 
 def pack_linear(w, bias, device, col_index=None, k_total=None, row_index=None, n_total=None) -> PackedConv:
@@ -80,7 +82,9 @@ def pack_linear(w, bias, device, col_index=None, k_total=None, row_index=None, n
     if bias is not None:
         b2[ri] = bias.double()
     kp = _round_up(kt, 16)
-    return pack_conv(w2.view(nt, kt, 1, 1), b2, 1, 0, device, cin_pad_to=kp)
+    pc = pack_conv(w2.view(nt, kt, 1, 1), b2, 1, 0, device, cin_pad_to=kp)
+    pc.macs_per_pixel = N * K
+    return pc
 
 
 # HMR state row layout (see hands_hmr_init_f32): feat | pose6d 96 | shape 10 | 2 pad | cam 3 | 1 pad

@@ -30,4 +30,4 @@ def recipe_model():
 
 @pytest.fixture(scope="session")
 def recipe_sd(recipe_model):
-    return {k: v.detach().clone() for k, v in recipe_model.state_dict().items()}
+    return {k: v.detach().cpu().clone() for k, v in recipe_model.state_dict().items()}
