@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--bz", type=int, default=256, help="samples per GPU per step (2 hands each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-bz", type=int, default=16)
+    ap.add_argument("--layer-report", default="", help="write a per-launch CSV of the GEMM kernel here")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,12 +112,15 @@ def main():
     events = []
     macs = [0]
 
+    launch_info = []
+
     def hook(phase, pc, npix):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream(dev))   # the stream the C ABI launches on
         events.append(ev)
         if phase == "begin":
             macs[0] += pc.macs_per_pixel * npix
+            launch_info.append((pc.Cin, pc.Cout, pc.KH, pc.stride, npix, pc.macs_per_pixel * npix))
 
     n_prof = 3
     HandsLight.conv_hook = staticmethod(hook)
@@ -129,6 +133,13 @@ def main():
     conv_ms = sum(durs_ms) / n_prof
     conv_flops = 2.0 * macs[0] / n_prof
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+    if args.layer_report:
+        with open(args.layer_report, "w") as fh:
+            fh.write("idx,Cin,Cout,k,stride,M,gflop,ms,tflops\n")
+            for i in range(launches):
+                ms = sum(durs_ms[i + r * launches] for r in range(n_prof)) / n_prof
+                cin, cout, k, st, npix, mc = launch_info[i]
+                fh.write(f"{i},{cin},{cout},{k},{st},{npix},{2 * mc / 1e9:.3f},{ms:.4f},{2 * mc / ms / 1e9:.2f}\n")
     roofline = {"bound": "mfma", "kernel": "conv_igemm_f32_kernel", "achieved": round(achieved, 2),
                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": None, "launches_per_step": launches,

@@ -25,6 +25,10 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+__device__ __forceinline__ float f4elem(const float4& v, int t) {
+  return t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w));
+}
+
 constexpr int BK = 16;         // floats per k-step
 constexpr int LDS_ROW = 20;    // padded LDS row (floats): 80 B = 5 x 16 B slots
 
@@ -96,48 +100,50 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
 #pragma unroll
   for (int i = 0; i < W_ROWS; ++i) wrow[i] = a.w + (size_t)(n0 + srow + 64 * i) * a.Kpad + chunk * 4;
 
+  // staging registers (explicit scalars-of-float4: arrays captured by lambdas ended up in scratch)
   float4 xr[A_ROWS], wr[W_ROWS];
   // k-step state (wave-uniform for the regular path)
   int kh = 0, kw = 0, c0 = 0;
   const int ntaps = a.KH * a.KW;
 
-  auto load_tiles = [&](int kt) {
-    if constexpr (STEM) {
-      // Cin == 4: every 16-byte chunk is its own filter tap
-      const int tap = kt * 4 + chunk;
-      const int tkh = tap / a.KW;
-      const int tkw = tap - tkh * a.KW;
-      const int toff = (tkh * a.W + tkw) * a.in_ps;
-#pragma unroll
-      for (int i = 0; i < A_ROWS; ++i) {
-        const bool ok = x_ok[i] && tap < ntaps && (unsigned)(x_hi0[i] + tkh) < (unsigned)a.H &&
-                        (unsigned)(x_wi0[i] + tkw) < (unsigned)a.W;
-        xr[i] = ok ? *reinterpret_cast<const float4*>(a.in + (x_base[i] + toff))
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    } else {
-      const int toff = (kh * a.W + kw) * a.in_ps + c0 + chunk * 4;
-#pragma unroll
-      for (int i = 0; i < A_ROWS; ++i) {
-        const bool ok = x_ok[i] && (unsigned)(x_hi0[i] + kh) < (unsigned)a.H &&
-                        (unsigned)(x_wi0[i] + kw) < (unsigned)a.W;
-        xr[i] = ok ? *reinterpret_cast<const float4*>(a.in + (x_base[i] + toff))
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      c0 += BK;
-      if (c0 >= a.Cin) { c0 = 0; if (++kw == a.KW) { kw = 0; ++kh; } }
-    }
-#pragma unroll
-    for (int i = 0; i < W_ROWS; ++i) wr[i] = *reinterpret_cast<const float4*>(wrow[i] + kt * BK);
-  };
-  auto store_tiles = [&](int buf) {
-    float* dx = sX + buf * BM * LDS_ROW + srow * LDS_ROW + chunk * 4;
-    float* dw = sW + buf * BN * LDS_ROW + srow * LDS_ROW + chunk * 4;
-#pragma unroll
-    for (int i = 0; i < A_ROWS; ++i) *reinterpret_cast<float4*>(dx + 64 * i * LDS_ROW) = xr[i];
-#pragma unroll
-    for (int i = 0; i < W_ROWS; ++i) *reinterpret_cast<float4*>(dw + 64 * i * LDS_ROW) = wr[i];
-  };
+#define LOAD_TILES(KT)                                                                              \
+  do {                                                                                              \
+    if constexpr (STEM) {                                                                           \
+      /* Cin == 4: every 16-byte chunk is its own filter tap */                                    \
+      const int tap = (KT) * 4 + chunk;                                                             \
+      const int tkh = tap / a.KW;                                                                   \
+      const int tkw = tap - tkh * a.KW;                                                             \
+      const int toff = (tkh * a.W + tkw) * a.in_ps;                                                 \
+      _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) {                                          \
+        const bool ok = x_ok[i] && tap < ntaps && (unsigned)(x_hi0[i] + tkh) < (unsigned)a.H &&     \
+                        (unsigned)(x_wi0[i] + tkw) < (unsigned)a.W;                                 \
+        xr[i] = ok ? *reinterpret_cast<const float4*>(a.in + (x_base[i] + toff))                    \
+                   : make_float4(0.f, 0.f, 0.f, 0.f);                                               \
+      }                                                                                             \
+    } else {                                                                                        \
+      const int toff = (kh * a.W + kw) * a.in_ps + c0 + chunk * 4;                                  \
+      _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) {                                          \
+        const bool ok = x_ok[i] && (unsigned)(x_hi0[i] + kh) < (unsigned)a.H &&                     \
+                        (unsigned)(x_wi0[i] + kw) < (unsigned)a.W;                                  \
+        xr[i] = ok ? *reinterpret_cast<const float4*>(a.in + (x_base[i] + toff))                    \
+                   : make_float4(0.f, 0.f, 0.f, 0.f);                                               \
+      }                                                                                             \
+      c0 += BK;                                                                                     \
+      if (c0 >= a.Cin) { c0 = 0; if (++kw == a.KW) { kw = 0; ++kh; } }                              \
+    }                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < W_ROWS; ++i)                                              \
+      wr[i] = *reinterpret_cast<const float4*>(wrow[i] + (KT) * BK);                                \
+  } while (0)
+
+#define STORE_TILES(BUF)                                                                            \
+  do {                                                                                              \
+    float* dx = sX + (BUF) * BM * LDS_ROW + srow * LDS_ROW + chunk * 4;                             \
+    float* dw = sW + (BUF) * BN * LDS_ROW + srow * LDS_ROW + chunk * 4;                             \
+    _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i)                                              \
+      *reinterpret_cast<float4*>(dx + 64 * i * LDS_ROW) = xr[i];                                    \
+    _Pragma("unroll") for (int i = 0; i < W_ROWS; ++i)                                              \
+      *reinterpret_cast<float4*>(dw + 64 * i * LDS_ROW) = wr[i];                                    \
+  } while (0)
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -148,8 +154,8 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = a.Kpad / BK;
-  load_tiles(0);
-  store_tiles(0);
+  LOAD_TILES(0);
+  STORE_TILES(0);
   __syncthreads();
 
   // fragment read offsets: row = lane&31, k half = lane>>5
@@ -157,69 +163,82 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   const float* fw = sW + (wn * 64) * LDS_ROW + frag;
   const float* fx = sX + (wm * 64) * LDS_ROW + frag;
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tiles(kt + 1);   // in flight under this step's MFMAs
+#define COMPUTE_STEP(BUF)                                                                           \
+  do {                                                                                              \
+    float4 wf[2][2], xf[2][2]; /* [32-row block][kk] */                                             \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                              \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                               \
+        wf[i][kk] = *reinterpret_cast<const float4*>(fw + (BUF) * BN * LDS_ROW + i * 32 * LDS_ROW + kk * 8); \
+        xf[i][kk] = *reinterpret_cast<const float4*>(fx + (BUF) * BM * LDS_ROW + i * 32 * LDS_ROW + kk * 8); \
+      }                                                                                             \
+    }                                                                                               \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                              \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                             \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                           \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4elem(wf[i][kk], t), f4elem(xf[j][kk], t), \
+                                                             acc[i][j], 0, 0, 0);                    \
+          }                                                                                         \
+        }                                                                                           \
+      }                                                                                             \
+    }                                                                                               \
+  } while (0)
 
-    float4 wf[2][2], xf[2][2];              // [32-row block][kk]
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        wf[i][kk] = *reinterpret_cast<const float4*>(fw + buf * BN * LDS_ROW + i * 32 * LDS_ROW + kk * 8);
-        xf[i][kk] = *reinterpret_cast<const float4*>(fx + buf * BM * LDS_ROW + i * 32 * LDS_ROW + kk * 8);
-      }
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const float wv = reinterpret_cast<const float*>(&wf[i][kk])[t];
-            const float xv = reinterpret_cast<const float*>(&xf[j][kk])[t];
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, xv, acc[i][j], 0, 0, 0);
-          }
-        }
-      }
-    }
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
+  // steady state: loads of step kt+1 are in flight under the 32 MFMAs of step kt
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    const int buf = kt & 1;
+    LOAD_TILES(kt + 1);
+    COMPUTE_STEP(buf);
+    STORE_TILES(buf ^ 1);
     __syncthreads();
   }
+  COMPUTE_STEP((nk - 1) & 1);
+#undef COMPUTE_STEP
 
   // ---- epilogue: D row = channel = 8*q + 4*(lane>>5) + e, D col = pixel = lane&31 ---------------
+  // All loads (bias, residual) use clamped, always-valid addresses and are issued as a batch per
+  // 32x32 block; only the stores are predicated.
   const int half = lane >> 5;
+  const int nb = n0 + wn * 64 + half * 4;
+  float4 bv[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const float4*>(a.bias + nb + i * 32 + q * 8);
+  const bool has_res = a.res != nullptr;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int m = m0 + wm * 64 + j * 32 + (lane & 31);
-    if (m >= a.M) continue;
-    float* orow = a.out + (size_t)m * a.out_ps;
-    const float* rrow = a.res ? a.res + (size_t)m * a.res_ps : nullptr;
+    const bool m_ok = m < a.M;
+    const int mc = m_ok ? m : a.M - 1;
+    float* orow = a.out + (size_t)mc * a.out_ps;
+    const float* rrow = has_res ? a.res + (size_t)mc * a.res_ps : a.bias;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      float4 rv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 64 + i * 32 + q * 8 + half * 4;
-        if (n >= a.N) continue;
-        const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+        const int n = nb + i * 32 + q * 8;
+        rv[q] = has_res ? *reinterpret_cast<const float4*>(rrow + (n < a.N ? n : 0))
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = nb + i * 32 + q * 8;
         float4 v;
-        v.x = acc[i][j][q * 4 + 0] + bv.x;
-        v.y = acc[i][j][q * 4 + 1] + bv.y;
-        v.z = acc[i][j][q * 4 + 2] + bv.z;
-        v.w = acc[i][j][q * 4 + 3] + bv.w;
-        if (rrow) {
-          const float4 rv = *reinterpret_cast<const float4*>(rrow + n);
-          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-        }
+        v.x = acc[i][j][q * 4 + 0] + bv[i][q].x + rv[q].x;
+        v.y = acc[i][j][q * 4 + 1] + bv[i][q].y + rv[q].y;
+        v.z = acc[i][j][q * 4 + 2] + bv[i][q].z + rv[q].z;
+        v.w = acc[i][j][q * 4 + 3] + bv[i][q].w + rv[q].w;
         if (a.relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        *reinterpret_cast<float4*>(orow + n) = v;
+        if (m_ok && n < a.N) *reinterpret_cast<float4*>(orow + n) = v;
       }
     }
   }
+#undef LOAD_TILES
+#undef STORE_TILES
 }
 
 template <int WAVES_M, int WAVES_N, bool STEM>
