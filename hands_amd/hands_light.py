@@ -266,6 +266,13 @@ class HandsLight(nn.Module):
         return self._packed
 
     # ---- buffers ------------------------------------------------------------------------------
+    def _side_stream(self, dev):
+        st = self._ws.get("side_stream")
+        if st is None or st.device != dev:
+            st = torch.cuda.Stream(device=dev)
+            self._ws["side_stream"] = st
+        return st
+
     def _buf(self, name, numel, dev):
         t = self._ws.get(name)
         if t is None or t.numel() < numel or t.device != dev:
@@ -275,6 +282,7 @@ class HandsLight(nn.Module):
 
     # ---- kernel launch helpers ----------------------------------------------------------------
     conv_hook = None   # bench.py installs a callback here to bracket every GEMM launch with events
+    overlap_trunks = True   # run the global trunk on a second HIP stream beside the hand trunk
 
     @staticmethod
     def _conv(L, pc: PackedConv, x, B, H, W, out, relu, stream, res=None, in_ps=None, out_ps=None,
@@ -286,12 +294,12 @@ class HandsLight(nn.Module):
                      pc.Kpad, 1 if relu else 0)
         hook = HandsLight.conv_hook
         if hook is not None:
-            hook("begin", pc, B * Ho * Wo)
+            hook("begin", pc, B * Ho * Wo, stream)
         check(L.hands_conv2d_nhwc_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
                                       ptr(res, res_off) if res is not None else None, ptr(out, out_off),
                                       stream), "hands_conv2d_nhwc_f32")
         if hook is not None:
-            hook("end", pc, B * Ho * Wo)
+            hook("end", pc, B * Ho * Wo, stream)
         return Ho, Wo
 
     def _trunk(self, L, P, x4, B, res_in, stream, tag, cap_B):
@@ -300,9 +308,9 @@ class HandsLight(nn.Module):
         H = W = res_in
         per = 112 * 112 * 64 * (res_in * res_in) // (224 * 224) + 64
         cap = cap_B * per
-        a = self._buf("trunk_a", cap, dev); b = self._buf("trunk_b", cap, dev)
-        t1 = self._buf("trunk_t1", cap, dev); t2 = self._buf("trunk_t2", cap, dev)
-        ds = self._buf("trunk_ds", cap, dev)
+        a = self._buf("trunk_a_" + tag, cap, dev); b = self._buf("trunk_b_" + tag, cap, dev)
+        t1 = self._buf("trunk_t1_" + tag, cap, dev); t2 = self._buf("trunk_t2_" + tag, cap, dev)
+        ds = self._buf("trunk_ds_" + tag, cap, dev)
         Ho, Wo = self._conv(L, P["stem"], x4, B, H, W, a, True, stream)
         check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(b), B, Ho, Wo, 64, stream), "maxpool")
         H, W = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
@@ -345,19 +353,32 @@ class HandsLight(nn.Module):
         stream = torch.cuda.current_stream(dev).cuda_stream
         buf = lambda n, numel: self._buf(n, numel, dev)
 
-        # -- trunks (model.py:193, 238-239); r and l crops share weights -> one 2*bz batch -------
+        # -- trunks (model.py:193, 238-239); r and l crops share weights -> one 2*bz batch.  The
+        #    global trunk runs on a second HIP stream so that its workgroups fill the tail of every
+        #    hand-trunk launch (and vice versa): the launches are 400-3000 blocks on 256 CUs.
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev) if HandsLight.overlap_trunks else main
+        ev0 = torch.cuda.Event()
+        ev0.record(main)
+        side.wait_event(ev0)
+        feat_vec = buf("feat_vec", bz * F)
+        x4g = buf("x4g", bz * res * res * 4)
+        s2 = side.cuda_stream
+        check(L.hands_nchw3_to_nhwc4_f32(ptr(img), ptr(x4g), bz, res, res, s2), "nchw->nhwc4")
+        featg, fh, fw = self._trunk(L, P["backbone"], x4g, bz, res, s2, "g", bz)
+        # sum-pool (model.py:196)
+        check(L.hands_sumpool_nhwc_f32(ptr(featg), ptr(feat_vec), bz, fh * fw, F, F, s2), "sumpool")
+        ev1 = torch.cuda.Event()
+        ev1.record(side)
         x4 = buf("x4", B2 * res * res * 4)
-        check(L.hands_nchw3_to_nhwc4_f32(ptr(img), ptr(x4), bz, res, res, stream), "nchw->nhwc4")
-        featg, fh, fw = self._trunk(L, P["backbone"], x4, bz, res, stream, "g", B2)
         check(L.hands_nchw3_to_nhwc4_f32(ptr(r_img), ptr(x4), bz, res, res, stream), "nchw->nhwc4")
         check(L.hands_nchw3_to_nhwc4_f32(ptr(l_img), ptr(x4, bz * res * res * 4), bz, res, res, stream),
               "nchw->nhwc4")
         feath, fh, fw = self._trunk(L, P["hand_backbone"], x4, B2, res, stream, "h", B2)
         HW = fh * fw
+        main.wait_event(ev1)
 
-        # -- sum-pool (model.py:196) and KPE concat (model.py:258-271) ---------------------------
-        feat_vec = buf("feat_vec", bz * F)
-        check(L.hands_sumpool_nhwc_f32(ptr(featg), ptr(feat_vec), bz, HW, F, F, stream), "sumpool")
+        # -- KPE concat (model.py:258-271) ----------------------------------------------------------
         center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
         corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0)
         Cc = F + 20 * self.n_freq
