@@ -1,0 +1,198 @@
+"""CPU tests of the host side: strict dict, packing identities, C-ABI library exports, sharding."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import hands_amd
+from hands_amd import _lib
+from hands_amd.dist import pack_predictions, shard_batch, shard_range, unpack_predictions
+from hands_amd.packing import fold_bn, hmr_state_columns, pack_conv, pack_linear, pack_mano
+from hands_amd.xdict import prefix_dict, xdict
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+# ---- xdict (reference: common/xdict.py) -----------------------------------------------------------
+def test_xdict_strict_assignment_and_merge():
+    d = xdict({"a": 1})
+    with pytest.raises(AssertionError):
+        d["a"] = 2                       # xdict.py:50-55
+    d.overwrite("a", 3)
+    assert d["a"] == 3
+    with pytest.raises(AssertionError):
+        d.merge({"a": 0})                # xdict.py:89-104
+    d.merge({"b": 2})
+    assert d.prefix("p.").sorted_keys() == ["p.a", "p.b"]
+    assert d.postfix(".r").sorted_keys() == ["a.r", "b.r"]
+    assert xdict({"cam_t/wp": 1}).replace_keys("/", ".").sorted_keys() == ["cam_t.wp"]
+    assert d.search("a").sorted_keys() == ["a"] and d.rm("a").sorted_keys() == ["b"]
+    assert d.subset(["b"]) == {"b": 2}
+    assert prefix_dict({"x": 1}, "mano.") == {"mano.x": 1}
+
+
+def test_xdict_detach_and_invalid(capsys):
+    d = xdict({"t": torch.ones(2, requires_grad=True) * 2, "l": [torch.zeros(1)], "s": "name"})
+    out = d.detach()
+    assert not out["t"].requires_grad and out["l"][0].device.type == "cpu" and out["s"] == "name"
+    assert not d.has_invalid()
+    assert xdict({"x": torch.tensor([float("nan")])}).has_invalid()
+    assert "nan" in capsys.readouterr().out
+    m = xdict({"v": torch.ones(2), "w": [torch.ones(1)]}).mul(2)
+    assert m["v"].tolist() == [2, 2] and m["w"][0].item() == 2
+
+
+# ---- packing --------------------------------------------------------------------------------------
+def _packed_conv_reference(pc, x_nhwc):
+    """Emulate the kernel's GEMM view on CPU with the PACKED weights (torch fp64)."""
+    B, H, W, C = x_nhwc.shape
+    x = x_nhwc.double().permute(0, 3, 1, 2)
+    w = pc.w.double()[:, : pc.KH * pc.KW * pc.Cin].view(-1, pc.KH, pc.KW, pc.Cin).permute(0, 3, 1, 2)
+    y = F.conv2d(x, w, pc.bias.double(), stride=pc.stride, padding=pc.pad)
+    return y[:, : pc.Cout]
+
+
+def test_pack_conv_bn_fold_matches_conv_then_bn():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 16, 9, 9, generator=g)
+    w = torch.randn(24, 16, 3, 3, generator=g)
+    bn = [torch.rand(24, generator=g) + 0.5, torch.randn(24, generator=g), torch.randn(24, generator=g),
+          torch.rand(24, generator=g) + 0.5]
+    ref = F.batch_norm(F.conv2d(x.double(), w.double(), stride=2, padding=1), bn[2].double(), bn[3].double(),
+                       bn[0].double(), bn[1].double(), False, 0.0, 1e-5)
+    pc = pack_conv(*fold_bn(w, *bn), 2, 1, "cpu")
+    assert pc.w.shape == (128, 144) and pc.Kpad == 144 and pc.Cout == 24 and pc.macs_per_pixel == 24 * 16 * 9
+    got = _packed_conv_reference(pc, x.permute(0, 2, 3, 1))
+    assert (got - ref).abs().max() < 1e-5
+    assert torch.all(pc.w[24:] == 0) and torch.all(pc.bias[24:] == 0)
+
+
+def test_pack_stem_pads_rgb_to_4():
+    w = torch.randn(64, 3, 7, 7)
+    pc = pack_conv(w, None, 2, 3, "cpu", cin_pad_to=4)
+    assert pc.Cin == 4 and pc.Kpad == 208 and pc.macs_per_pixel == 64 * 147
+    wk = pc.w[:64, :196].view(64, 7, 7, 4)
+    assert torch.equal(wk[..., :3], w.permute(0, 2, 3, 1)) and torch.all(wk[..., 3] == 0)
+
+
+def test_hmr_state_and_grasp_column_permutations():
+    F_ = 32
+    cols = hmr_state_columns(F_)
+    assert len(cols) == F_ + 109 and len(set(cols)) == len(cols) and max(cols) == F_ + 110
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(8, F_ + 109, generator=g)
+    b = torch.randn(8, generator=g)
+    pc = pack_linear(w, b, "cpu", col_index=cols, k_total=F_ + 112)
+    feat, pose, shape, cam = (torch.randn(3, n, generator=g) for n in (F_, 96, 10, 3))
+    row = torch.zeros(3, F_ + 112)
+    row[:, :F_], row[:, F_:F_ + 96], row[:, F_ + 96:F_ + 106], row[:, F_ + 108:F_ + 111] = feat, pose, shape, cam
+    ref = F.linear(torch.cat([feat, pose, shape, cam], 1), w, b)
+    got = F.linear(row, pc.w[:8, : F_ + 112], pc.bias[:8])
+    assert (got - ref).abs().max() < 1e-5
+    # decoders stacked in state order with residual columns
+    rows = list(range(96)) + [96 + i for i in range(10)] + [108 + i for i in range(3)]
+    wd = torch.randn(109, 16, generator=g)
+    pd = pack_linear(wd, None, "cpu", row_index=rows, n_total=112)
+    assert pd.Cout == 112 and torch.equal(pd.w[108:111, :16], wd[106:109]) and torch.all(pd.w[106:108] == 0)
+
+
+def test_pack_mano_blend_matrix_reproduces_blendshapes():
+    a = hands_amd.synthetic_mano_asset(True)
+    mp = pack_mano(a, "cpu")
+    g = torch.Generator().manual_seed(2)
+    beta, pf = torch.randn(4, 10, generator=g).double(), torch.randn(4, 135, generator=g).double()
+    row = torch.zeros(4, 160, dtype=torch.float64)
+    row[:, :10], row[:, 10:145] = beta, pf
+    got = row @ mp["blend"].w.double()[:2336].T + mp["blend"].bias.double()[:2336]
+    ref = (torch.from_numpy(a.v_template).double()[None] +
+           torch.einsum("bl,mkl->bmk", beta, torch.from_numpy(a.shapedirs).double())).reshape(4, -1) + \
+        pf @ torch.from_numpy(a.posedirs).double()
+    assert (got[:, :2334] - ref).abs().max() < 1e-7 and torch.all(got[:, 2334:] == 0)
+    J = torch.from_numpy(a.J_regressor).double() @ (ref - pf @ torch.from_numpy(a.posedirs).double()).view(4, 778, 3)
+    J2 = mp["J_template"].double()[None] + (mp["J_shapedirs"].double() @ beta.T).T.reshape(4, 16, 3)
+    assert (J - J2).abs().max() < 1e-6
+
+
+# ---- C-ABI library -------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "hands_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(hands_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    declared -= {"hands_conv_desc", "hands_mano_consts", "hands_mano_out"}
+    assert declared == set(_lib.SIGNATURES) | set(_lib.EXTRA_SYMBOLS), declared ^ (set(_lib.SIGNATURES) | set(_lib.EXTRA_SYMBOLS))
+    L = _lib.lib()                                   # loads without a GPU
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.hands_abi_version() == 1
+    assert L.hands_error_string(0) == b"ok" and b"invalid" in L.hands_error_string(10001)
+    assert ctypes.sizeof(_lib.ConvDesc) == 16 * 4
+
+
+def test_bad_descriptors_are_rejected_without_a_gpu():
+    L = _lib.lib()
+    d = _lib.ConvDesc(1, 7, 7, 30, 7, 7, 64, 1, 1, 1, 0, 30, 64, 0, 32, 0)      # Cin % 4 != 0
+    assert L.hands_conv2d_nhwc_f32(ctypes.byref(d), 16, 16, 16, None, 16, None) == 10001
+    assert L.hands_conv2d_nhwc_f32(None, 16, 16, 16, None, 16, None) == 10001
+    assert L.hands_maxpool3x3s2_nhwc_f32(16, 16, 1, 8, 8, 6, None) == 10001
+    with pytest.raises(RuntimeError):
+        _lib.check(10001, "x")
+
+
+def test_product_refuses_cpu_tensors(recipe_model):
+    inputs, meta = hands_amd.synthetic_inputs(1, 0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        recipe_model(inputs, meta)
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "hands_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert "oracle" not in txt.replace("the oracle", "").replace("oracle/", ""), f
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_unsupported_switches_fail_loudly():
+    a = dict(hands_amd.DEFAULT_ARGS)
+    a["tf_decoder"] = True
+    with pytest.raises(NotImplementedError):
+        hands_amd.HandsLight(args=type(hands_amd.DEFAULT_ARGS)(a))
+    with pytest.raises(NotImplementedError):
+        hands_amd.HandsLight(backbone="resnet18")
+
+
+def test_state_dict_roundtrip_and_wrapper_prefix(recipe_model):
+    m2 = hands_amd.HandsLight()
+    ck = {"model." + k: v for k, v in recipe_model.state_dict().items()}         # Lightning-style checkpoint
+    missing = m2.load_state_dict({k[len("model."):]: v for k, v in ck.items()}, strict=False)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert torch.equal(m2.state_dict()["head_r.hmr_layer.decoders.cam_t/wp.weight"],
+                       recipe_model.state_dict()["head_r.hmr_layer.decoders.cam_t/wp.weight"])
+    assert m2._packed is None
+    assert recipe_model.mano_r.faces.shape == (1538, 3) and recipe_model.mano_r.faces.dtype == np.int64
+    assert np.array_equal(recipe_model.mano_l.faces, hands_amd.synthetic_mano_asset(False).faces)   # bit-exact pass-through
+
+
+# ---- sharding helpers ----------------------------------------------------------------------------
+def test_shard_ranges_cover_the_batch():
+    for bz in (1, 7, 8, 256):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(bz, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == bz
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+def test_shard_and_pack_roundtrip():
+    inputs, meta = hands_amd.synthetic_inputs(6, 0, img_res=8)
+    meta["imgname"] = [f"{i}.jpg" for i in range(6)]
+    parts = [shard_batch(inputs, meta, r, 4) for r in range(4)]
+    assert torch.equal(torch.cat([p[0]["r_img"] for p in parts]), inputs["r_img"])
+    assert sum((p[1]["imgname"] for p in parts), []) == meta["imgname"]
+    out = {"a": torch.randn(3, 778, 3), "b": torch.randn(3, 16, 3, 3), "c": torch.randn(3, 9)}
+    flat, layout = pack_predictions(out)
+    back = unpack_predictions(flat, layout)
+    assert flat.shape == (3, 778 * 3 + 144 + 9) and all(torch.equal(back[k], out[k]) for k in out)
