@@ -72,6 +72,8 @@ def main():
     model = hands_amd.apply_recipe(hands_amd.HandsLight())
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model = model.to(dev).eval()
+    if os.environ.get("HANDS_CHUNKS"):
+        HandsLight.trunk_chunks = tuple(int(v) for v in os.environ["HANDS_CHUNKS"].split(","))
     bz = args.bz
     inputs, meta = hands_amd.synthetic_inputs(bz, seed=rank, device=dev)
 
@@ -114,9 +116,14 @@ def main():
 
     launch_info = []
 
+    main_stream = torch.cuda.current_stream(dev)
+
     def hook(phase, pc, npix, stream_handle):
+        # the instrumented forward runs on ONE stream (overlap_trunks=False): the stream handed to
+        # the C ABI is torch's current stream, so the events bracket exactly this launch
+        assert stream_handle == main_stream.cuda_stream
         ev = torch.cuda.Event(enable_timing=True)
-        ev.record(torch.cuda.ExternalStream(stream_handle, device=dev))   # the stream the C ABI launches on
+        ev.record(main_stream)
         events.append(ev)
         if phase == "begin":
             macs[0] += pc.macs_per_pixel * npix

@@ -266,11 +266,11 @@ class HandsLight(nn.Module):
         return self._packed
 
     # ---- buffers ------------------------------------------------------------------------------
-    def _side_stream(self, dev):
-        st = self._ws.get("side_stream")
+    def _side_stream(self, dev, name="side_stream"):
+        st = self._ws.get(name)
         if st is None or st.device != dev:
             st = torch.cuda.Stream(device=dev)
-            self._ws["side_stream"] = st
+            self._ws[name] = st
         return st
 
     def _buf(self, name, numel, dev):
@@ -283,6 +283,7 @@ class HandsLight(nn.Module):
     # ---- kernel launch helpers ----------------------------------------------------------------
     conv_hook = None   # bench.py installs a callback here to bracket every GEMM launch with events
     overlap_trunks = True   # run the global trunk on a second HIP stream beside the hand trunk
+    trunk_chunks = (1, 2)   # (global, hand) trunk jobs, one HIP stream each
 
     @staticmethod
     def _conv(L, pc: PackedConv, x, B, H, W, out, relu, stream, res=None, in_ps=None, out_ps=None,
@@ -302,7 +303,7 @@ class HandsLight(nn.Module):
             hook("end", pc, B * Ho * Wo, stream)
         return Ho, Wo
 
-    def _trunk(self, L, P, x4, B, res_in, stream, tag, cap_B):
+    def _trunk(self, L, P, x4, B, res_in, stream, tag, cap_B, out=None, x_off=0, out_off=0):
         """ResNet-50 trunk on an NHWC4 batch; returns (B,7,7,2048) features (flat tensor)."""
         dev = x4.device
         H = W = res_in
@@ -311,7 +312,7 @@ class HandsLight(nn.Module):
         a = self._buf("trunk_a_" + tag, cap, dev); b = self._buf("trunk_b_" + tag, cap, dev)
         t1 = self._buf("trunk_t1_" + tag, cap, dev); t2 = self._buf("trunk_t2_" + tag, cap, dev)
         ds = self._buf("trunk_ds_" + tag, cap, dev)
-        Ho, Wo = self._conv(L, P["stem"], x4, B, H, W, a, True, stream)
+        Ho, Wo = self._conv(L, P["stem"], x4, B, H, W, a, True, stream, x_off=x_off)
         check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(b), B, Ho, Wo, 64, stream), "maxpool")
         H, W = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
         cur, nxt = b, a
@@ -324,8 +325,10 @@ class HandsLight(nn.Module):
                 ident = ds
             else:
                 ident = cur
-            dst = nxt if i + 1 < nblk else self._buf("feat_" + tag, B * H2 * W2 * e["c3"].Cout, dev)
-            self._conv(L, e["c3"], t2, B, H2, W2, dst, True, stream, res=ident)
+            last = i + 1 == nblk
+            dst = nxt if not last else (out if out is not None else
+                                        self._buf("feat_" + tag, B * H2 * W2 * e["c3"].Cout, dev))
+            self._conv(L, e["c3"], t2, B, H2, W2, dst, True, stream, res=ident, out_off=out_off if last else 0)
             H, W = H2, W2
             cur, nxt = dst, cur
             if i + 1 == nblk:
@@ -353,30 +356,50 @@ class HandsLight(nn.Module):
         stream = torch.cuda.current_stream(dev).cuda_stream
         buf = lambda n, numel: self._buf(n, numel, dev)
 
-        # -- trunks (model.py:193, 238-239); r and l crops share weights -> one 2*bz batch.  The
-        #    global trunk runs on a second HIP stream so that its workgroups fill the tail of every
-        #    hand-trunk launch (and vice versa): the launches are 400-3000 blocks on 256 CUs.
+        # -- trunks (model.py:193, 238-239).  r and l crops share `hand_backbone`, so the 2*bz crops
+        #    are one batch; the 3*bz trunk passes are cut into `trunk_chunks` jobs that run on separate
+        #    HIP streams: each conv launch is only 400-3000 workgroups on 256 CUs, and workgroups of
+        #    the other streams fill its tail (and HBM-bound layers overlap with MFMA-bound ones).
         main = torch.cuda.current_stream(dev)
-        side = self._side_stream(dev) if HandsLight.overlap_trunks else main
-        ev0 = torch.cuda.Event()
-        ev0.record(main)
-        side.wait_event(ev0)
         feat_vec = buf("feat_vec", bz * F)
         x4g = buf("x4g", bz * res * res * 4)
-        s2 = side.cuda_stream
-        check(L.hands_nchw3_to_nhwc4_f32(ptr(img), ptr(x4g), bz, res, res, s2), "nchw->nhwc4")
-        featg, fh, fw = self._trunk(L, P["backbone"], x4g, bz, res, s2, "g", bz)
-        # sum-pool (model.py:196)
-        check(L.hands_sumpool_nhwc_f32(ptr(featg), ptr(feat_vec), bz, fh * fw, F, F, s2), "sumpool")
-        ev1 = torch.cuda.Event()
-        ev1.record(side)
         x4 = buf("x4", B2 * res * res * 4)
+        featg = buf("feat_g", bz * 49 * F)
+        feath = buf("feat_h", B2 * 49 * F)
+        gch, hch = HandsLight.trunk_chunks if HandsLight.overlap_trunks else (1, 1)
+        gch, hch = max(1, min(gch, bz)), max(1, min(hch, B2))
+        jobs = []   # (weights, images, x4 buffer, first sample, n samples, out buffer, is_global)
+        for c in range(gch):
+            lo, hi = c * bz // gch, (c + 1) * bz // gch
+            jobs.append((P["backbone"], x4g, lo, hi - lo, featg, True))
+        for c in range(hch):
+            lo, hi = c * B2 // hch, (c + 1) * B2 // hch
+            jobs.append((P["hand_backbone"], x4, lo, hi - lo, feath, False))
+        check(L.hands_nchw3_to_nhwc4_f32(ptr(img), ptr(x4g), bz, res, res, stream), "nchw->nhwc4")
         check(L.hands_nchw3_to_nhwc4_f32(ptr(r_img), ptr(x4), bz, res, res, stream), "nchw->nhwc4")
         check(L.hands_nchw3_to_nhwc4_f32(ptr(l_img), ptr(x4, bz * res * res * 4), bz, res, res, stream),
               "nchw->nhwc4")
-        feath, fh, fw = self._trunk(L, P["hand_backbone"], x4, B2, res, stream, "h", B2)
+        ev0 = torch.cuda.Event()
+        ev0.record(main)
+        fh = fw = 7
+        done = []
+        for ji, (Pt, xb, lo, n, ob, is_g) in enumerate(jobs):
+            # the largest job (last) stays on the caller's stream
+            st = main if (ji == len(jobs) - 1 or not HandsLight.overlap_trunks) else self._side_stream(dev, f"side{ji}")
+            if st is not main:
+                st.wait_event(ev0)
+            _, fh, fw = self._trunk(L, Pt, xb, n, res, st.cuda_stream, f"j{ji}", n, out=ob,
+                                    x_off=lo * res * res * 4, out_off=lo * 49 * F)
+            if st is not main:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                done.append(ev)
+        for ev in done:          # join only after every job has been enqueued
+            main.wait_event(ev)
+        assert fh * fw == 49
         HW = fh * fw
-        main.wait_event(ev1)
+        # sum-pool (model.py:196)
+        check(L.hands_sumpool_nhwc_f32(ptr(featg), ptr(feat_vec), bz, HW, F, F, stream), "sumpool")
 
         # -- KPE concat (model.py:258-271) ----------------------------------------------------------
         center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
