@@ -17,7 +17,10 @@ c_float_p = C.c_void_p  # raw device pointers travel as integers
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "B", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad",
-        "in_pix_stride", "out_pix_stride", "res_pix_stride", "Kpad", "relu")]
+        "in_pix_stride", "out_pix_stride", "res_pix_stride", "Kpad", "act")]
+
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_LEAKY_RELU = 0, 1, 2, 3
 
 
 class ManoConsts(C.Structure):
@@ -44,6 +47,13 @@ SIGNATURES = {
     "hands_grasp_input_f32": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "hands_mano_pose_f32": [C.POINTER(ManoConsts), _P, _P, _I, _P, _I, _P, _P, _I, _P],
     "hands_mano_skin_f32": [C.POINTER(ManoConsts), _P, _I, _P, _P, _P, _P, _F, _F, C.POINTER(ManoOut), _I, _P],
+    "hands_resize_crop_nchw3_to_nhwc4_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hands_layernorm_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "hands_add_pos_f32": [_P, _P, _P, _I, _I, _I, _P],
+    "hands_kpe_encode_f32": [_P, _P, _P, _I, _I, _I, _P],
+    "hands_attention_f32": [_P, _P, _I, _I, _I, _I, _F, _P],
+    "hands_cross_attention_1q_f32": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "hands_rot6d_to_matrix_cols_f32": [_P, _I, _P, _I, _P],
 }
 EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string")
 

@@ -25,6 +25,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// nn.GELU() (exact, erf form): x * 0.5 * (1 + erf(x / sqrt(2)))
+__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+
 __device__ __forceinline__ float f4elem(const float4& v, int t) {
   return t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w));
 }
@@ -230,8 +233,13 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
         v.y = acc[i][j][q * 4 + 1] + bv[i][q].y + rv[q].y;
         v.z = acc[i][j][q * 4 + 2] + bv[i][q].z + rv[q].z;
         v.w = acc[i][j][q * 4 + 3] + bv[i][q].w + rv[q].w;
-        if (a.relu) {
+        if (a.relu == HANDS_ACT_RELU) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        } else if (a.relu == HANDS_ACT_GELU) {
+          v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+        } else if (a.relu == HANDS_ACT_LEAKY_RELU) {
+          v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;
+          v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;
         }
         if (m_ok && n < a.N) *reinterpret_cast<float4*>(orow + n) = v;
       }
@@ -273,7 +281,7 @@ extern "C" int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, 
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
-  a.relu = d->relu;
+  a.relu = d->act;
   hipStream_t s = (hipStream_t)stream;
   if (stem) return (d->Cout <= 64) ? launch<4, 1, true>(a, s) : launch<2, 2, true>(a, s);
   return (d->Cout <= 64) ? launch<4, 1, false>(a, s) : launch<2, 2, false>(a, s);

@@ -112,6 +112,49 @@ class MANOHead(nn.Module):
         return self.mano.faces
 
 
+def run_mano_heads(L, mano_r, mano_l, rot, shape, cam, cam_init, K, img_res, bz, stream, buf):
+    """MANOHead.forward for the right (rows [0,bz)) and left (rows [bz,2bz)) hands
+    (src/nets/hand_heads/mano_head.py:21-65) + the `cam_t.wp.init` / `mano.` prefixing of
+    model.py:392-399.  rot (2bz,16,3,3), shape (2bz,10), cam / cam_init (2bz,3), K (bz,3,3)."""
+    dev = rot.device
+    blend_in = buf("blend_in", bz * 160)
+    Abuf, j16 = buf("mano_A", bz * 192), buf("mano_j16", bz * 48)
+    vposed = buf("vposed", bz * 2336)
+    output = xdict()
+    for side, (mp, post) in enumerate(((mano_r, ".r"), (mano_l, ".l"))):
+        ro = side * bz
+        check(L.hands_mano_pose_f32(C.byref(mp["consts"]), ptr(rot, ro * 144), ptr(shape, ro * 10), 10,
+                                    ptr(blend_in), 160, ptr(Abuf), ptr(j16), bz, stream), "mano_pose")
+        HandsLight._conv(L, mp["blend"], blend_in, bz, 1, 1, vposed, False, stream)
+        o = {"vertices": torch.empty(bz, 778, 3, device=dev), "joints3d": torch.empty(bz, 21, 3, device=dev),
+             "v3d.cam": torch.empty(bz, 778, 3, device=dev), "j3d.cam": torch.empty(bz, 21, 3, device=dev),
+             "j2d.norm": torch.empty(bz, 21, 2, device=dev), "cam_t": torch.empty(bz, 3, device=dev)}
+        mo = ManoOut(ptr(o["vertices"]), ptr(o["joints3d"]), ptr(o["v3d.cam"]), ptr(o["j3d.cam"]),
+                     ptr(o["j2d.norm"]), ptr(o["cam_t"]))
+        check(L.hands_mano_skin_f32(C.byref(mp["consts"]), ptr(vposed), 2336, ptr(Abuf), ptr(j16),
+                                    ptr(cam, ro * 3), ptr(K), img_res, 0.1, C.byref(mo), bz, stream),
+              "mano_skin")
+        md = xdict()                                           # key order of mano_head.py:53-61
+        md["cam_t.wp"] = cam[ro:ro + bz]
+        md["cam_t"] = o["cam_t"]
+        md["joints3d"] = o["joints3d"]
+        md["vertices"] = o["vertices"]
+        md["j3d.cam"] = o["j3d.cam"]
+        md["v3d.cam"] = o["v3d.cam"]
+        md["j2d.norm"] = o["j2d.norm"]
+        md["beta"] = shape[ro:ro + bz]
+        md["pose"] = rot[ro:ro + bz]
+        md = md.postfix(post)
+        md["cam_t.wp.init" + post] = cam_init[ro:ro + bz]       # model.py:392-393
+        output.merge(prefix_dict(md, "mano."))                  # model.py:395-399
+    return output
+
+
+def mano_consts(m):
+    return ManoConsts(ptr(m["pose_mean"]), ptr(m["J_template"]), ptr(m["J_shapedirs"]), ptr(m["lbs_weights"]),
+                      ptr(m["tip_ids"]))
+
+
 class _Args(dict):
     """attribute *and* ``.get`` access, like the reference's EasyDict args (parser.py:39-58)."""
 
@@ -255,8 +298,7 @@ class HandsLight(nn.Module):
         P["mano_l"] = pack_mano(self.mano_l.mano.asset(), dev)
         for side in ("mano_r", "mano_l"):
             m = P[side]
-            m["consts"] = ManoConsts(ptr(m["pose_mean"]), ptr(m["J_template"]), ptr(m["J_shapedirs"]),
-                                     ptr(m["lbs_weights"]), ptr(m["tip_ids"]))
+            m["consts"] = mano_consts(m)
         return P
 
     def packed(self, dev):
@@ -291,8 +333,9 @@ class HandsLight(nn.Module):
         Ho = (H + 2 * pc.pad - pc.KH) // pc.stride + 1
         Wo = (W + 2 * pc.pad - pc.KW) // pc.stride + 1
         d = ConvDesc(B, H, W, pc.Cin, Ho, Wo, pc.Cout, pc.KH, pc.KW, pc.stride, pc.pad,
-                     in_ps or pc.Cin, out_ps or pc.Cout, (res_ps or pc.Cout) if res is not None else 0,
-                     pc.Kpad, 1 if relu else 0)
+                     in_ps or pc.Cin, out_ps or pc.Cout,
+                     (pc.Cout if res_ps is None else res_ps) if res is not None else 0,
+                     pc.Kpad, int(relu))   # relu: bool or a HANDS_ACT_* code
         hook = HandsLight.conv_hook
         if hook is not None:
             hook("begin", pc, B * Ho * Wo, stream)
@@ -455,36 +498,8 @@ class HandsLight(nn.Module):
               "flip_swap")
 
         # -- MANOHead x2 (mano_head.py:21-65) -----------------------------------------------------
-        blend_in = buf("blend_in", bz * 160)
-        Abuf, j16 = buf("mano_A", bz * 192), buf("mano_j16", bz * 48)
-        vposed = buf("vposed", bz * 2336)
-        output = xdict()
-        for side, (mp, post) in enumerate(((P["mano_r"], ".r"), (P["mano_l"], ".l"))):
-            ro = side * bz
-            check(L.hands_mano_pose_f32(C.byref(mp["consts"]), ptr(rot_m, ro * 144), ptr(shape_m, ro * 10), 10,
-                                        ptr(blend_in), 160, ptr(Abuf), ptr(j16), bz, stream), "mano_pose")
-            self._conv(L, mp["blend"], blend_in, bz, 1, 1, vposed, False, stream)
-            o = {"vertices": torch.empty(bz, 778, 3, device=dev), "joints3d": torch.empty(bz, 21, 3, device=dev),
-                 "v3d.cam": torch.empty(bz, 778, 3, device=dev), "j3d.cam": torch.empty(bz, 21, 3, device=dev),
-                 "j2d.norm": torch.empty(bz, 21, 2, device=dev), "cam_t": torch.empty(bz, 3, device=dev)}
-            mo = ManoOut(ptr(o["vertices"]), ptr(o["joints3d"]), ptr(o["v3d.cam"]), ptr(o["j3d.cam"]),
-                         ptr(o["j2d.norm"]), ptr(o["cam_t"]))
-            check(L.hands_mano_skin_f32(C.byref(mp["consts"]), ptr(vposed), 2336, ptr(Abuf), ptr(j16),
-                                        ptr(cam_m, ro * 3), ptr(K), float(self.img_res), 0.1, C.byref(mo),
-                                        bz, stream), "mano_skin")
-            md = xdict()                                           # key order of mano_head.py:53-61
-            md["cam_t.wp"] = cam_m[ro:ro + bz]
-            md["cam_t"] = o["cam_t"]
-            md["joints3d"] = o["joints3d"]
-            md["vertices"] = o["vertices"]
-            md["j3d.cam"] = o["j3d.cam"]
-            md["v3d.cam"] = o["v3d.cam"]
-            md["j2d.norm"] = o["j2d.norm"]
-            md["beta"] = shape_m[ro:ro + bz]
-            md["pose"] = rot_m[ro:ro + bz]
-            md = md.postfix(post)
-            md["cam_t.wp.init" + post] = caminit_m[ro:ro + bz]      # model.py:392-393
-            output.merge(prefix_dict(md, "mano."))                  # model.py:395-399
+        output = run_mano_heads(L, P["mano_r"], P["mano_l"], rot_m, shape_m, cam_m, caminit_m, K,
+                                float(self.img_res), bz, stream, buf)
 
         # -- grasp classifier on the UN-flipped HMR outputs (model.py:401-411) -------------------
         gld = P["g0"].Cin

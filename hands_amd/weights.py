@@ -41,6 +41,17 @@ def recipe_tensor(key: str, ref: torch.Tensor) -> torch.Tensor | None:
         return torch.zeros_like(ref)
     g = _gen(key)
     shape = tuple(ref.shape)
+    parts = key.split(".")
+    if leaf.startswith("init_"):
+        return None  # hamer mean-parameter buffers come from mano_mean_params, not from the recipe
+    if leaf == "pos_embed":
+        return (0.2 * torch.randn(shape, generator=g)).to(ref.dtype)
+    if leaf == "pos_embedding":
+        return torch.randn(shape, generator=g).to(ref.dtype)
+    if len(parts) >= 2 and parts[-2] in ("norm", "norm1", "norm2", "last_norm"):   # LayerNorm
+        if leaf == "weight":
+            return (1.0 + 0.1 * torch.randn(shape, generator=g)).to(ref.dtype)
+        return (0.1 * torch.randn(shape, generator=g)).to(ref.dtype)
     if _is_bn(key):
         if leaf == "weight":
             w = 1.0 + 0.1 * torch.randn(shape, generator=g)
@@ -66,6 +77,10 @@ def recipe_tensor(key: str, ref: torch.Tensor) -> torch.Tensor | None:
             w = 0.02 * w
         if key.endswith("cam_init.4.weight"):
             w = 0.1 * w
+        if key.endswith(("attn.proj.weight", "mlp.fc2.weight", "to_out.0.weight", "fn.net.3.weight")):
+            w = 0.5 * w    # transformer residual branches (hamer_light)
+        if key.endswith(("decpose.weight", "decshape.weight", "deccam.weight")):
+            w = 0.02 * w
         if key.startswith("feature_conv.0") or key.startswith("grasp_classifier.0"):
             w = 0.25 * w  # inputs are sums of O(1) feature maps (crop+glb, 49-pixel sum-pool)
         return w.to(ref.dtype)
@@ -75,6 +90,10 @@ def recipe_tensor(key: str, ref: torch.Tensor) -> torch.Tensor | None:
             b = 0.1 * torch.randn(shape, generator=g)   # x3 iterations: joint rotations of ~0.3 rad
         elif ".decoders.shape." in key:
             b = 0.3 * torch.randn(shape, generator=g)   # betas O(1)
+        if key.endswith("decpose.bias"):
+            b = 0.3 * torch.randn(shape, generator=g)
+        elif key.endswith("decshape.bias"):
+            b = 0.5 * torch.randn(shape, generator=g)
         if key.endswith("cam_init.4.bias"):
             b = b + torch.tensor([1.0, 0.0, 0.0])  # weak-perspective scale near 1
         return b.to(ref.dtype)
@@ -89,6 +108,14 @@ def apply_recipe(module: torch.nn.Module) -> torch.nn.Module:
         if val is not None:
             sd[key].copy_(val)
     return module
+
+
+def synthetic_mano_mean_params():
+    """Stand-in for hamer's ``mano_mean_params.npz`` (pose (96,), shape (10,), cam (3,)); the real
+    file lives under $DATA_DIR/hamer/_DATA/data (src/models/hamer_light/mano_head.py:49-56)."""
+    import numpy as np
+    return {"pose": np.tile(np.array([1, 0, 0, 0, 1, 0], np.float32), 16), "shape": np.zeros(10, np.float32),
+            "cam": np.array([0.9, 0.0, 0.0], np.float32)}
 
 
 def synthetic_inputs(bz: int, seed: int = 0, img_res: int = 224, device="cpu"):

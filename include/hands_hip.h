@@ -36,7 +36,7 @@ const char* hands_error_string(int code);
 /* ---------------------------------------------------------------------------------------------
  * Convolution / linear layer as implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32).
  *   out[m, n] = act( bias[n] + sum_k patch(m, k) * w[n, k]  (+ residual[m, n]) )
- *   m = (b, ho, wo) flattened, k = (kh, kw, cin) flattened, act = ReLU if relu != 0.
+ *   m = (b, ho, wo) flattened, k = (kh, kw, cin) flattened, act selected by desc.act.
  * Replaces nn.Conv2d + eval-mode BatchNorm2d (folded into w/bias by the host) + ReLU + the
  * bottleneck's residual add: src/nets/backbone/resnet.py:134-154,264-280; feature_conv
  * model.py:91-101; and every nn.Linear of the heads (H=W=KH=KW=1): hand_hmr.py:34-40,
@@ -55,8 +55,13 @@ typedef struct hands_conv_desc {
   int32_t out_pix_stride;    /* floats between consecutive output pixels (>= Cout) */
   int32_t res_pix_stride;    /* floats between consecutive residual pixels; ignored if residual==NULL */
   int32_t Kpad;              /* packed weight row length */
-  int32_t relu;
+  int32_t act;               /* HANDS_ACT_*: epilogue activation after bias (+ residual) */
 } hands_conv_desc;
+
+#define HANDS_ACT_NONE 0
+#define HANDS_ACT_RELU 1
+#define HANDS_ACT_GELU 2        /* nn.GELU(): x*0.5*(1+erf(x/sqrt(2)))  (vit.py:76, pose_transformer.py:44) */
+#define HANDS_ACT_LEAKY_RELU 3  /* negative slope 0.01 (handoccnet_light/backbone.py) */
 
 int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
                           const float* bias, const float* residual, float* out,
@@ -149,6 +154,45 @@ int hands_mano_skin_f32(const hands_mano_consts* c, const float* v_posed, int ld
                         const float* A, const float* joints16, const float* cam_wp,
                         const float* K, float img_res, float min_s, const hands_mano_out* out,
                         int B, hands_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * hamer_light (ViT-H/16 + cross-attention decoder head): src/models/hamer_light/.
+ * GEMMs (patch embed, qkv, proj, MLP, to_kv, decoders ...) run on hands_conv2d_nhwc_f32.
+ * --------------------------------------------------------------------------------------------- */
+
+/* F.interpolate(bilinear, align_corners=False) (Hin,Win)->(S,S) of an NCHW (B,3,..) batch, keep
+ * columns [col0, col0+Wc), write NHWC4 (B,S,Wc,4).  hamer_light/model.py:82-100. */
+int hands_resize_crop_nchw3_to_nhwc4_f32(const float* in, float* out, int B, int Hin, int Win, int S,
+                                         int col0, int Wc, hands_stream_t stream);
+
+/* LayerNorm over the last dim C in {256,1024,1280}; out = LN(x)*gamma+beta (+ addvec[row/rows_per_vec]).
+ * vit.py:128-151,338 (eps 1e-6), pose_transformer.py:22-33 (eps 1e-5); the optional add is the KPE
+ * re-added to the final feature map (hamer_light/model.py:102-104). */
+int hands_layernorm_f32(const float* x, const float* gamma, const float* beta, float* out,
+                        const float* addvec, int rows_per_vec, int M, int C, float eps,
+                        hands_stream_t stream);
+
+/* x[b,t,:] = ((x[b,t,:] + pos[1+t,:]) + pos[0,:]) + vec[b,:]   (vec may be NULL).  vit.py:326-330. */
+int hands_add_pos_f32(float* x, const float* pos, const float* vec, int B, int T, int C,
+                      hands_stream_t stream);
+
+/* rows [center_enc 4L | corner_enc 16L | 0-pad] of the key-point encoding (pos_emb.py:53-67). */
+int hands_kpe_encode_f32(const float* center_angle, const float* corner_angle, float* out, int B, int ld,
+                         int n_freq, hands_stream_t stream);
+
+/* softmax((scale*q) k^T) v per (batch, head) on fp32 MFMA.  qkv rows are tokens: [q | k | v], each
+ * heads*head_dim wide (vit.py:110-126).  Built for T=192, head_dim=80 (ViT-H/16 at 256x192). */
+int hands_attention_f32(const float* qkv, float* out, int B, int T, int heads, int head_dim, float scale,
+                        hands_stream_t stream);
+
+/* one query token per sample against T context tokens: q (B, heads*64), kv rows [k | v] (B*T,
+ * 2*heads*64) -> out (B, heads*64); dots = (q.k)*scale (pose_transformer.py:113-123). */
+int hands_cross_attention_1q_f32(const float* q, const float* kv, float* out, int B, int T, int heads,
+                                 int head_dim, float scale, hands_stream_t stream);
+
+/* rot6d_to_rotmat with b1,b2,b3 as COLUMNS (hamer_light/geometry.py:47-62). */
+int hands_rot6d_to_matrix_cols_f32(const float* pose6d, int ld6, float* rotmat, int B,
+                                   hands_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,159 @@
+"""GPU parity tests of the hamer_light path through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import hands_amd
+from hands_amd import _lib
+from hands_amd._lib import ACT_GELU, check, ptr
+from hands_amd.hands_light import HandsLight
+from hands_amd.mano import synthetic_mano_asset
+from hands_amd.packing import pack_linear
+from hands_amd.weights import synthetic_inputs
+from oracle import hamer_oracle as H
+from oracle import hands_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def test_resize_crop_vs_torch():
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 3, 224, 224, generator=g)
+    ref = F.interpolate(x, size=256, mode="bilinear", align_corners=False)[:, :, :, 32:-32]
+    xd = x.to(DEV)
+    out = torch.empty(3, 256, 192, 4, device=DEV)
+    check(L.hands_resize_crop_nchw3_to_nhwc4_f32(ptr(xd), ptr(out), 3, 224, 224, 256, 32, 192, _stream()))
+    o = out.cpu()
+    assert (o[..., :3].permute(0, 3, 1, 2) - ref).abs().max().item() < 2e-6 and torch.all(o[..., 3] == 0)
+
+
+@pytest.mark.parametrize("C,eps", [(1280, 1e-6), (1024, 1e-5)])
+def test_layernorm_vs_torch(C, eps):
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(1)
+    x = 3 * torch.randn(37, C, generator=g) + 0.5
+    gam, bet = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    vec = torch.randn(10, C, generator=g)
+    ref = F.layer_norm(x.double(), (C,), gam.double(), bet.double(), eps)
+    d = [t.to(DEV) for t in (x, gam, bet, vec)]
+    out = torch.empty(37, C, device=DEV)
+    check(L.hands_layernorm_f32(ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(out), None, 1, 37, C, eps, _stream()))
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+    check(L.hands_layernorm_f32(ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(out), ptr(d[3]), 4, 37, C, eps, _stream()))
+    ref2 = ref + vec.double()[torch.arange(37) // 4]
+    assert (out.cpu().double() - ref2).abs().max().item() < 2e-5
+
+
+def test_vit_attention_vs_oracle():
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(2)
+    B, T, heads, D = 3, 192, 16, 80
+    C = heads * D
+    qkv = torch.randn(B, T, 3 * C, generator=g)
+    q, k, v = qkv.double().reshape(B, T, 3, heads, D).permute(2, 0, 3, 1, 4)
+    ref = ((q * D ** -0.5) @ k.transpose(-2, -1)).softmax(-1) @ v
+    ref = ref.transpose(1, 2).reshape(B, T, C)
+    qd = qkv.to(DEV)
+    out = torch.full((B, T, C), float("nan"), device=DEV)
+    check(L.hands_attention_f32(ptr(qd), ptr(out), B, T, heads, D, float(D ** -0.5), _stream()))
+    assert (out.cpu().double() - ref).abs().max().item() < 5e-6
+
+
+def test_cross_attention_vs_oracle():
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    B, T, heads, D = 5, 192, 8, 64
+    q = torch.randn(B, heads * D, generator=g)
+    kv = torch.randn(B, T, 2 * heads * D, generator=g)
+    k, v = kv.double().chunk(2, dim=-1)
+    sp = lambda z: z.view(B, -1, heads, D).transpose(1, 2)
+    a = (sp(q.double()[:, None]) @ sp(k).transpose(-1, -2) * D ** -0.5).softmax(-1)
+    ref = (a @ sp(v)).transpose(1, 2).reshape(B, heads * D)
+    qd, kvd = q.to(DEV), kv.to(DEV)
+    out = torch.empty(B, heads * D, device=DEV)
+    check(L.hands_cross_attention_1q_f32(ptr(qd), ptr(kvd), ptr(out), B, T, heads, D, float(D ** -0.5), _stream()))
+    assert (out.cpu().double() - ref).abs().max().item() < 5e-6
+
+
+def test_gelu_gemm_addpos_kpe_rot6d():
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(70, 1280, generator=g)
+    w, b = torch.randn(512, 1280, generator=g) / 36, torch.randn(512, generator=g)
+    pc = pack_linear(w, b, DEV)
+    xd = x.to(DEV)
+    out = torch.empty(70, 512, device=DEV)
+    HandsLight._conv(L, pc, xd, 70, 1, 1, out, ACT_GELU, _stream())
+    ref = F.gelu(F.linear(x.double(), w.double(), b.double()))
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+    # broadcast residual row (res_pix_stride = 0), used for "dec(token) + mean params"
+    row = torch.randn(512, generator=g).to(DEV)
+    HandsLight._conv(L, pc, xd, 70, 1, 1, out, 0, _stream(), res=row, res_ps=0)
+    ref = F.linear(x.double(), w.double(), b.double()) + row.cpu().double()
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+    # add_pos
+    xt = torch.randn(2, 192, 1280, generator=g)
+    pos, vec = torch.randn(193, 1280, generator=g), torch.randn(2, 1280, generator=g)
+    d = [t.to(DEV) for t in (xt, pos, vec)]
+    check(L.hands_add_pos_f32(ptr(d[0]), ptr(d[1]), ptr(d[2]), 2, 192, 1280, _stream()))
+    ref = ((xt + pos[None, 1:]) + pos[None, :1]) + vec[:, None]
+    assert torch.equal(d[0].cpu(), ref)
+    # kpe encode
+    ce, co = 0.5 * torch.randn(4, 2, generator=g), 0.5 * torch.randn(4, 8, generator=g)
+    dd = [ce.to(DEV), co.to(DEV)]
+    enc = torch.empty(4, 80, device=DEV)
+    check(L.hands_kpe_encode_f32(ptr(dd[0]), ptr(dd[1]), ptr(enc), 4, 80, 4, _stream()))
+    ref = torch.cat([O.pos_enc(ce), O.pos_enc(co)], 1)
+    assert (enc.cpu() - ref).abs().max().item() < 1e-6
+    # rot6d (columns)
+    d6 = torch.randn(6, 112, generator=g)
+    d6d = d6.to(DEV)
+    rot = torch.empty(6, 16, 3, 3, device=DEV)
+    check(L.hands_rot6d_to_matrix_cols_f32(ptr(d6d), 112, ptr(rot), 6, _stream()))
+    ref = H.rot6d_to_rotmat_columns(d6[:, :96].reshape(-1, 6)).view(6, 16, 3, 3)
+    assert (rot.cpu() - ref).abs().max().item() < 5e-6
+
+
+@pytest.fixture(scope="module")
+def hamer_gpu():
+    m = hands_amd.apply_recipe(hands_amd.HAMER())
+    return m.eval().to(DEV)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_hamer_forward_vs_golden(golden_dir, hamer_gpu, seed):
+    d = np.load(os.path.join(golden_dir, f"hamer_light_bz2_seed{seed}.npz"))
+    inputs, meta_info = synthetic_inputs(2, seed, device=DEV)
+    out = hamer_gpu(inputs, meta_info)
+    torch.cuda.synchronize()
+    keys = [k[4:] for k in d.files if k.startswith("out/")]
+    assert list(out.keys()) == keys or sorted(out.keys()) == sorted(keys)
+    assert len(out) == 22
+    for k in keys:
+        ref, got = d["out/" + k], out[k].cpu().numpy()
+        assert got.shape == ref.shape and out[k].is_contiguous(), k
+        tol = 2e-3 if k.startswith("grasp") else 1e-4
+        np.testing.assert_allclose(got, ref, rtol=tol, atol=tol, err_msg=k)
+    for hn in "rl":
+        verr = np.abs(out[f"mano.vertices.{hn}"].cpu().numpy() - d[f"out/mano.vertices.{hn}"]).max()
+        mp = O.mpjpe_ra_mm(out[f"mano.joints3d.{hn}"].cpu(), torch.from_numpy(d[f"out/mano.joints3d.{hn}"]))
+        print(f"hamer seed {seed} hand {hn}: max vertex err {verr:.3e} m, MPJPE {mp:.3e} mm")
+        assert verr < 1e-6 and mp < 1e-3, (verr, mp)
+
+
+def test_hamer_batch_independence(hamer_gpu):
+    inputs, meta_info = synthetic_inputs(6, 3, device=DEV)
+    big = {k: v.clone() for k, v in hamer_gpu(inputs, meta_info).items()}
+    small = hamer_gpu({k: v[:2].contiguous() for k, v in inputs.items()},
+                      {k: v[:2].contiguous() for k, v in meta_info.items()})
+    for k in small:
+        assert torch.equal(big[k][:2], small[k]), k
