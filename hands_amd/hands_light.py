@@ -338,12 +338,12 @@ class HandsLight(nn.Module):
                      pc.Kpad, int(relu))   # relu: bool or a HANDS_ACT_* code
         hook = HandsLight.conv_hook
         if hook is not None:
-            hook("begin", pc, B * Ho * Wo, stream)
+            hook("begin", pc, B * Ho * Wo, stream, res is not None)
         check(L.hands_conv2d_nhwc_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
                                       ptr(res, res_off) if res is not None else None, ptr(out, out_off),
                                       stream), "hands_conv2d_nhwc_f32")
         if hook is not None:
-            hook("end", pc, B * Ho * Wo, stream)
+            hook("end", pc, B * Ho * Wo, stream, res is not None)
         return Ho, Wo
 
     def _trunk(self, L, P, x4, B, res_in, stream, tag, cap_B, out=None, x_off=0, out_off=0):

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Fold rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/r01_pmc_<workload>.json (dev tool).
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <workload> <out.json>
+HBM bytes = 2 * FETCH_SIZE (KB; gfx950 reports half of a wide coalesced read stream, MI355X_MICROARCH.md
+section HBM) + WRITE_SIZE (KB), summed over every conv_igemm_f32_kernel dispatch of the run."""
+import csv
+import json
+import sys
+
+fetch_csv, write_csv, workload, out = sys.argv[1:5]
+
+
+def total(fn, counter):
+    tot, disp = 0.0, set()
+    for r in csv.DictReader(open(fn)):
+        if "conv_igemm_f32_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            tot += float(r["Counter_Value"])
+            disp.add(r["Dispatch_Id"])
+    return tot, len(disp)
+
+
+f, nf = total(fetch_csv, "FETCH_SIZE")
+w, nw = total(write_csv, "WRITE_SIZE")
+assert nf == nw and nf > 0, (nf, nw)
+res = {"workload": workload, "kernel": "conv_igemm_f32_kernel", "dispatches": nf,
+       "fetch_size_kb_sum": f, "write_size_kb_sum": w, "fetch_correction": 2.0,
+       "hbm_gb_per_launch": (2.0 * f + w) * 1024 / nf / 1e9,
+       "read_gb_per_launch": 2.0 * f * 1024 / nf / 1e9, "write_gb_per_launch": w * 1024 / nf / 1e9,
+       "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --workload {workload} "
+                  "--serial --steps 1 --warmup 1 --no-cpu-baseline"}
+json.dump(res, open(out, "w"), indent=1)
+print(res)
