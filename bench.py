@@ -59,8 +59,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bz", type=int, default=0, help="samples per GPU per step (2 hands each); "
                     "default 256 (hands_light) / 64 (hamer_light)")
-    ap.add_argument("--workload", default="hands_light", choices=["hands_light", "hamer_light"],
-                    help="hands_light = BASELINE.json configs[1] (the headline metric); hamer_light = configs[2]")
+    ap.add_argument("--workload", default="hands_light", choices=["hands_light", "hamer_light", "handoccnet_light"],
+                    help="hands_light = BASELINE.json configs[1] (the headline metric); hamer_light = configs[2]; "
+                         "handoccnet_light = configs[3] (bz = 256/8 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true",
                     help="one HIP stream for everything (every launch alone on the chip): the mode the "
@@ -86,9 +87,12 @@ def main():
     from hands_amd.hands_light import HandsLight
 
     hamer = args.workload == "hamer_light"
+    handocc = args.workload == "handoccnet_light"
     if not args.bz:
-        args.bz = 64 if hamer else 256
-    model = hands_amd.apply_recipe(hands_amd.HAMER() if hamer else hands_amd.HandsLight())
+        args.bz = {"hamer_light": 64, "handoccnet_light": 32}.get(args.workload, 256)
+    ctor = {"hamer_light": hands_amd.HAMER, "handoccnet_light": hands_amd.HandOccNet}.get(args.workload, hands_amd.HandsLight)
+    model = hands_amd.apply_recipe(ctor())
+    flop_per_hand = {"hamer_light": 251e9, "handoccnet_light": 36.2e9}.get(args.workload, 12.77e9)
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model = model.to(dev).eval()
     if args.serial:
@@ -191,7 +195,7 @@ def main():
     parity = None
     if not args.no_cpu_baseline:
         from oracle import hands_oracle as O
-        cb = 2 if hamer else args.cpu_bz
+        cb = 2 if hamer else (8 if handocc else args.cpu_bz)
         ci, cm = hands_amd.synthetic_inputs(cb, seed=0)
         ar, al = hands_amd.synthetic_mano_asset(True), hands_amd.synthetic_mano_asset(False)
         cores = host_cores()
@@ -200,6 +204,9 @@ def main():
         if hamer:
             from oracle import hamer_oracle as HO
             oracle_fwd = HO.hamer_forward
+        elif handocc:
+            from oracle import handoccnet_oracle as HOC
+            oracle_fwd = HOC.handoccnet_forward
         else:
             oracle_fwd = O.hands_light_forward
         for nthreads in sorted({max(1, cores // 2), cores}):
@@ -231,12 +238,14 @@ def main():
         "data": "synthetic",
         "config": {"workload": (f"hamer_light ViT-H/16 (256x192) + decoder head + MANO, bz={bz} samples/GPU "
                                 f"({2 * bz} crops = hands)" if hamer else
+                                f"handoccnet_light LeakyReLU ResNet-50 + FPN + FIT/SET + hourglass regressor + MANO, "
+                                f"256x256, bz={bz} samples/GPU ({2 * bz} crops = hands)" if handocc else
                                 "hands_light ResNet-50 x3 + feature_conv + HMR + MANO, 224x224, "
                                 f"bz={bz} samples/GPU ({2 * bz} hands, {3 * bz} trunk passes)"),
                    "per_gpu_batch": bz, "global_batch": bz * n_gpus, "img_res": 224,
                    "parallelism": f"dp{n_gpus}" + ("+allgather" if n_gpus > 1 else "")},
         "hands_per_sec_per_gpu": round(hands_per_s / n_gpus, 1),
-        "path_tflops": round(hands_per_s * (251e9 if hamer else 12.77e9) / 1e12 / n_gpus, 2),
+        "path_tflops": round(hands_per_s * flop_per_hand / 1e12 / n_gpus, 2),
         "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
     }
     print(json.dumps(line), flush=True)

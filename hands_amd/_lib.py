@@ -54,6 +54,17 @@ SIGNATURES = {
     "hands_attention_f32": [_P, _P, _I, _I, _I, _I, _F, _P],
     "hands_cross_attention_1q_f32": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "hands_rot6d_to_matrix_cols_f32": [_P, _I, _P, _I, _P],
+    "hands_upsample_bilinear_add_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hands_pool2x2_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "hands_channel_pool_f32": [_P, _P, C.c_longlong, _I, _P],
+    "hands_gate_apply_f32": [_P, _P, _I, _P, _P, C.c_longlong, _I, _P],
+    "hands_add_embed2_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "hands_add_rowvec_f32": [_P, _P, _P, _I, _I, _I, _P],
+    "hands_token_sum_f32": [_P, _P, _I, _I, _I, _P],
+    "hands_bn_leaky_f32": [_P, _P, _P, _P, C.c_longlong, _I, _P],
+    "hands_upsample_nearest2x_add_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "hands_spatial_softmax_f32": [_P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "hands_flash_attention_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
 }
 EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string")
 

@@ -1,0 +1,371 @@
+"""``HandOccNet`` -- the handoccnet_light forward path on MI355X.
+
+Mirror of the reference ``HandOccNet(focal_length, img_res, args)``
+(src/models/handoccnet_light/model.py:17-129): same forward contract, 22 output keys and the same 906
+``state_dict`` tensors (the parameter tree is materialised from ``manifests/handoccnet_light.json``).
+
+    statement                                              kernel
+    model.py:66-70    resize 224->256, cat                 hands_resize_crop_nchw3_to_nhwc4_f32
+    backbone.py:44-53 LeakyReLU ResNet-50                  hands_conv2d_nhwc_f32 (BN folded, LEAKY epilogue)
+    backbone.py:54-62 FPN top-down, smooth, avg-pool       conv + hands_upsample_bilinear_add_f32 + hands_pool2x2
+    cbam.py:72-82     SpatialGate                          hands_channel_pool_f32, 7x7 conv, hands_gate_apply_f32
+    transformer.py    FIT / SET (2 blocks each)            hands_add_embed2_f32, 1x1 convs, hands_flash_attention_f32
+                                                           (fp32 MFMA, FIT gate fused), LayerNorm, GELU MLP, 3x3 fusion
+    hand_head.py      hourglass, heat-maps, encoder        hands_bn_leaky_f32 + conv (pre-activation units),
+                                                           hands_pool2x2, hands_upsample_nearest2x_add_f32,
+                                                           hands_spatial_softmax_f32
+    mano_head.py:190-207 MLP regressor, rot6d (columns)    GEMMs, hands_rot6d_to_matrix_cols_f32
+    model.py:103-120  MANOHead x2, grasp MLP               shared with hands_light
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, check, ptr
+from .hands_light import HandsLight, MANOHead, _Args, mano_consts, run_mano_heads
+from .packing import BN_EPS, PackedConv, pack_conv, pack_linear, pack_mano
+from .param_tree import build_tree, load_manifest
+from .xdict import xdict
+
+HANDOCC_DEFAULT_ARGS = _Args(pos_enc="center+corner_latent", n_freq_pos_enc=4, use_grasp_loss=True,
+                             use_render_seg_loss=False, img_res=224, focal_length=1000.0,
+                             method="handoccnet_light")
+NTOK, CF, HEADS = 1024, 256, 4
+
+
+class HandOccNet(nn.Module):
+    def __init__(self, focal_length=1000.0, img_res=224, args=None, mano_assets=None):
+        super().__init__()
+        args = args if args is not None else HANDOCC_DEFAULT_ARGS
+        get = args.get if hasattr(args, "get") else (lambda k, d=None: getattr(args, k, d))
+        self.args = args
+        if get("pos_enc") != "center+corner_latent" or not get("use_grasp_loss", False) or \
+                get("use_render_seg_loss", False):
+            raise NotImplementedError("hands_amd.HandOccNet: only the shipped default switches are built")
+        self.n_freq = int(get("n_freq_pos_enc", 4))
+        self.input_size = (256, 256)
+        build_tree(self, load_manifest("handoccnet_light"))
+        assets = mano_assets or (None, None)
+        self.mano_r = MANOHead(True, focal_length, img_res, assets[0])
+        self.mano_l = MANOHead(False, focal_length, img_res, assets[1])
+        # hand_regHead grid buffers (hand_head.py:24-28); only consumed by the unused 2-D read-out
+        rng = torch.arange(32).float()
+        vv, uu = torch.meshgrid(rng, rng, indexing="ij")
+        self.regressor.hand_regHead.uu.copy_((uu + 0.5) / 32)
+        self.regressor.hand_regHead.vv.copy_((vv + 0.5) / 32)
+        self.pos_enc = get("pos_enc")
+        self.use_grasp_loss = True
+        self.img_res, self.focal_length = img_res, focal_length
+        self._packed = None
+        self._packed_dev = None
+        self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_packed())
+
+    def invalidate_packed(self):
+        self._packed = None
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate_packed()
+        return super()._apply(fn, *a, **k)
+
+    # ---- packing ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _pack(self, dev):
+        sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
+
+        def bn_affine(p, eps=BN_EPS):
+            s = sd[p + ".weight"].double() / torch.sqrt(sd[p + ".running_var"].double() + eps)
+            return s, sd[p + ".bias"].double() - sd[p + ".running_mean"].double() * s
+
+        def conv(p, stride=1, pad=0, bn=None, cin_pad_to=None):
+            """conv (+ optional bias) followed by an optional eval-BatchNorm, folded."""
+            w = sd[p + ".weight"].double()
+            b = sd[p + ".bias"].double() if (p + ".bias") in sd else torch.zeros(w.shape[0], dtype=torch.float64)
+            if bn is not None:
+                s, t = bn_affine(bn)
+                w, b = w * s.view(-1, 1, 1, 1), b * s + t
+            return pack_conv(w, b, stride, pad, dev, cin_pad_to=cin_pad_to)
+
+        def lin(p, **kw):
+            return pack_linear(sd[p + ".weight"], sd[p + ".bias"], dev, **kw)
+
+        def preact(p):
+            s, t = bn_affine(p)
+            return s.float().to(dev), t.float().to(dev)
+
+        P = {"stem": conv("backbone.layer0.0", 2, 3, bn="backbone.layer0.1", cin_pad_to=4), "layers": []}
+        for li, n in enumerate((3, 4, 6, 3), start=1):
+            blocks = []
+            for bi in range(n):
+                p = f"backbone.layer{li}.0.{bi}"
+                stride = 2 if (bi == 0 and li > 1) else 1
+                e = {"c1": conv(p + ".conv1", bn=p + ".bn1"), "c2": conv(p + ".conv2", stride, 1, bn=p + ".bn2"),
+                     "c3": conv(p + ".conv3", bn=p + ".bn3")}
+                if (p + ".downsample.0.weight") in sd:
+                    e["ds"] = conv(p + ".downsample.0", stride, 0, bn=p + ".downsample.1")
+                blocks.append(e)
+            P["layers"].append(blocks)
+        for name in ("toplayer", "latlayer1", "latlayer2", "latlayer3"):
+            P[name] = conv("backbone." + name)
+        P["smooth3"] = conv("backbone.smooth3", 1, 1)
+        P["gate"] = conv("backbone.attention_module.spatial.conv", 1, 3, bn="backbone.attention_module.spatial.bn",
+                         cin_pad_to=4)
+        P["kpe0"], P["kpe2"] = lin("kpe.feat_mlp.0"), lin("kpe.feat_mlp.2")
+        for T, inj in (("FIT", True), ("SET", False)):
+            layers = []
+            for i in range(2):
+                p = f"{T}.layers.{i}"
+                tokmaj = lambda e: e[0].permute(1, 2, 0).reshape(NTOK, CF).contiguous().to(dev)
+                e = {"v": conv(p + ".encode_value"), "q": conv(p + ".encode_query"), "k": conv(p + ".encode_key"),
+                     "qemb": tokmaj(sd[p + ".q_embedding"]), "kemb": tokmaj(sd[p + ".k_embedding"]),
+                     "n2": (sd[p + ".norm2.weight"].to(dev), sd[p + ".norm2.bias"].to(dev)),
+                     "fc1": lin(p + ".mlp.fc1"), "fc2": lin(p + ".mlp.fc2")}
+                if inj:
+                    e["q2"], e["k2"] = conv(p + ".encode_query2"), conv(p + ".encode_key2")
+                layers.append(e)
+            P[T] = layers
+        P["fit_c10"], P["fit_c12"] = conv("FIT.conv1.0", 1, 1), conv("FIT.conv1.2", 1, 1)
+        P["fit_c20"] = conv("FIT.conv2.0")
+
+        def hg_unit(p):      # hand_head.py:152-190
+            return {"pre": preact(p + ".bn1"), "c1": conv(p + ".conv1", bn=p + ".bn2"),
+                    "c2": conv(p + ".conv2", 1, 1, bn=p + ".bn3"), "c3": conv(p + ".conv3")}
+
+        def enc_unit(p):     # hand_head.py:117-149
+            return {"pre": preact(p + ".bn"), "c1": conv(p + ".conv1", bn=p + ".bn1"),
+                    "c2": conv(p + ".conv2", 1, 1, bn=p + ".bn2"), "c3": conv(p + ".conv3")}
+
+        hp = "regressor.hand_regHead"
+        P["hg"] = [[hg_unit(f"{hp}.hg.0.hg.{lvl}.{j}.0") for j in range(4 if lvl == 0 else 3)] for lvl in range(4)]
+        P["res"] = hg_unit(hp + ".res.0.0")
+        P["fc"] = conv(hp + ".fc.0.block.0", bn=hp + ".fc.0.block.1")
+        P["score"] = conv(hp + ".score.0")
+        P["betas"] = sd[hp + ".betas"].reshape(-1).contiguous().to(dev)
+        ep = "regressor.hand_Encoder"
+        P["hm_conv"] = conv(ep + ".heatmap_conv", cin_pad_to=32)
+        P["enc_conv"] = conv(ep + ".encoding_conv")
+        P["enc"] = [enc_unit(f"{ep}.reg.{i}") for i in range(8)]
+        mp = "regressor.mano_regHead"
+        # NCHW flatten of (B,256,2,2): reference column c*4 + hw; NHWC buffer column hw*256 + c
+        col = [(k % 4) * 256 + (k // 4) for k in range(1024)]
+        P["base0"] = lin(mp + ".mano_base_layer.0", col_index=col)
+        P["base2"] = lin(mp + ".mano_base_layer.2")
+        wd = torch.cat([sd[mp + ".pose_reg.weight"], sd[mp + ".shape_reg.weight"], sd[mp + ".cam_reg.weight"]], 0)
+        bd = torch.cat([sd[mp + ".pose_reg.bias"], sd[mp + ".shape_reg.bias"], sd[mp + ".cam_reg.bias"]], 0)
+        rows = list(range(96)) + [96 + i for i in range(10)] + [108 + i for i in range(3)]
+        P["regs"] = pack_linear(wd, bd, dev, row_index=rows, n_total=112)
+        gcol = [144 + i for i in range(10)] + list(range(144))
+        P["g0"] = lin("grasp_classifier.0", col_index=gcol, k_total=154)
+        P["g2"], P["g4"] = lin("grasp_classifier.2"), lin("grasp_classifier.4")
+        P["g6"] = lin("grasp_classifier.6", n_total=12)
+        for side, head in (("mano_r", self.mano_r), ("mano_l", self.mano_l)):
+            m = pack_mano(head.mano.asset(), dev)
+            m["consts"] = mano_consts(m)
+            P[side] = m
+        return P
+
+    def packed(self, dev):
+        if self._packed is None or self._packed_dev != dev:
+            self._packed = self._pack(dev)
+            self._packed_dev = dev
+        return self._packed
+
+    # ---- forward ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, inputs, meta_info, targets=None):
+        L = _lib.lib()
+        r_img = inputs["r_img"]
+        dev = r_img.device
+        if dev.type != "cuda":
+            raise RuntimeError("hands_amd.HandOccNet runs on a HIP device only (no CPU fallback)")
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+        r_img, l_img, K = f32(r_img), f32(inputs["l_img"]), f32(meta_info["intrinsics"])
+        bz, c, Hin, Win = r_img.shape
+        assert c == 3 and l_img.shape == r_img.shape and K.shape[1:] == (3, 3)
+        B2 = 2 * bz
+        P = self.packed(dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+
+        def conv(pc: PackedConv, x, B, H, W, act=ACT_NONE, res=None, out=None, **kw):
+            Ho = (H + 2 * pc.pad - pc.KH) // pc.stride + 1
+            Wo = (W + 2 * pc.pad - pc.KW) // pc.stride + 1
+            out = out if out is not None else new(B, Ho, Wo, pc.Cout)
+            HandsLight._conv(L, pc, x, B, H, W, out, act, stream, res=res, **kw)
+            return out, Ho, Wo
+
+        # -- model.py:66-70: resize to 256x256, cat(r, l) -> NHWC4 ---------------------------------
+        S = 256
+        x4 = new(B2, S, S, 4)
+        for side, im in enumerate((r_img, l_img)):
+            check(L.hands_resize_crop_nchw3_to_nhwc4_f32(ptr(im), ptr(x4, side * bz * S * S * 4), bz, Hin, Win, S, 0, S,
+                                                         stream), "resize")
+        # -- KPE embedding (hamer_light/pos_emb.py:28-64, feat_dim 256) ----------------------------
+        center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
+        corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0)
+        enc = new(B2, P["kpe0"].Cin)
+        check(L.hands_kpe_encode_f32(ptr(center), ptr(corner), ptr(enc), B2, P["kpe0"].Cin, self.n_freq, stream), "kpe")
+        k1, _, _ = conv(P["kpe0"], enc, B2, 1, 1, ACT_RELU)
+        kpe, _, _ = conv(P["kpe2"], k1, B2, 1, 1, ACT_RELU)
+        kpe = kpe.view(B2, CF)
+        # -- LeakyReLU ResNet-50 (backbone.py:44-53) ------------------------------------------------
+        a, H, W = conv(P["stem"], x4, B2, S, S, ACT_LEAKY_RELU)
+        Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        cur = new(B2, Hp, Wp, 64)
+        check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(cur), B2, H, W, 64, stream), "maxpool")
+        H, W = Hp, Wp
+        stages = []
+        for blocks in P["layers"]:
+            for e in blocks:
+                t1, _, _ = conv(e["c1"], cur, B2, H, W, ACT_LEAKY_RELU)
+                t2, H2, W2 = conv(e["c2"], t1, B2, H, W, ACT_LEAKY_RELU)
+                ident = conv(e["ds"], cur, B2, H, W)[0] if "ds" in e else cur
+                cur, _, _ = conv(e["c3"], t2, B2, H2, W2, ACT_LEAKY_RELU, res=ident)
+                H, W = H2, W2
+            stages.append((cur, H, W))
+        (c2, h2, w2), (c3, h3, w3), (c4, h4, w4), (c5, h5, w5) = stages
+        # -- FPN top-down (backbone.py:54-62) ------------------------------------------------------
+        def up_add(x, h, w, y, Hh, Ww):
+            out = new(B2, Hh, Ww, CF)
+            check(L.hands_upsample_bilinear_add_f32(ptr(x), ptr(y), ptr(out), B2, h, w, Hh, Ww, CF, stream), "up_add")
+            return out
+        p5, _, _ = conv(P["toplayer"], c5, B2, h5, w5)
+        p4 = up_add(p5, h5, w5, conv(P["latlayer1"], c4, B2, h4, w4)[0], h4, w4)
+        p3 = up_add(p4, h4, w4, conv(P["latlayer2"], c3, B2, h3, w3)[0], h3, w3)
+        p2 = up_add(p3, h3, w3, conv(P["latlayer3"], c2, B2, h2, w2)[0], h2, w2)
+        p2, _, _ = conv(P["smooth3"], p2, B2, h2, w2)          # smooth2(p3) of the reference is dead code
+        Hf, Wf = h2 // 2, w2 // 2
+        assert Hf * Wf == NTOK
+        pooled = new(B2, Hf, Wf, CF)
+        check(L.hands_pool2x2_nhwc_f32(ptr(p2), ptr(pooled), B2, h2, w2, CF, 0, stream), "avgpool")
+        # -- SpatialGate (cbam.py:72-82) ------------------------------------------------------------
+        npix = B2 * NTOK
+        comp = new(npix, 4)
+        check(L.hands_channel_pool_f32(ptr(pooled), ptr(comp), npix, CF, stream), "channel_pool")
+        logit, _, _ = conv(P["gate"], comp, B2, Hf, Wf)
+        primary, secondary = new(npix, CF), new(npix, CF)
+        dbg = self.__dict__.get("_debug")
+        check(L.hands_gate_apply_f32(ptr(pooled), ptr(logit), 4, ptr(primary), ptr(secondary), npix, CF, stream), "gate")
+
+        # -- FIT / SET (transformer.py:26-35,117-157) ------------------------------------------------
+        scale = float((CF // HEADS) ** -0.5)
+
+        def block(e, query, key, injection):
+            qe, ke = new(npix, CF), new(npix, CF)
+            check(L.hands_add_embed2_f32(ptr(query), ptr(key), ptr(e["qemb"]), ptr(e["kemb"]), ptr(kpe), ptr(qe), ptr(ke),
+                                         B2, NTOK, CF, stream), "add_embed")
+            v = conv(e["v"], key, npix, 1, 1)[0]
+            q = conv(e["q"], qe, npix, 1, 1)[0]
+            k = conv(e["k"], ke, npix, 1, 1)[0]
+            x = new(npix, CF)
+            if injection:
+                q2 = conv(e["q2"], qe, npix, 1, 1)[0]
+                k2 = conv(e["k2"], ke, npix, 1, 1)[0]
+                k2sum = new(B2, CF)
+                check(L.hands_token_sum_f32(ptr(k2), ptr(k2sum), B2, NTOK, CF, stream), "token_sum")
+                check(L.hands_flash_attention_f32(ptr(q), ptr(k), ptr(v), ptr(q2), ptr(k2sum), None, ptr(x), B2, NTOK,
+                                                  HEADS, CF // HEADS, scale, stream), "flash_attention")
+            else:
+                check(L.hands_flash_attention_f32(ptr(q), ptr(k), ptr(v), None, None, ptr(query), ptr(x), B2, NTOK,
+                                                  HEADS, CF // HEADS, scale, stream), "flash_attention")
+            y = new(npix, CF)
+            check(L.hands_layernorm_f32(ptr(x), ptr(e["n2"][0]), ptr(e["n2"][1]), ptr(y), None, 1, npix, CF, 1e-5, stream),
+                  "layernorm")
+            hdn = conv(e["fc1"], y, npix, 1, 1, ACT_GELU)[0]
+            conv(e["fc2"], hdn, npix, 1, 1, res=x, out=x)
+            return x
+
+        out = secondary
+        for e in P["FIT"]:
+            out = block(e, out, primary, True)
+        cat = torch.cat([primary.view(npix, CF), out.view(npix, CF)], dim=1)          # (npix, 512)
+        c20 = conv(P["fit_c20"], cat, B2, Hf, Wf)[0]
+        c10 = conv(P["fit_c10"], cat, B2, Hf, Wf, ACT_RELU)[0]
+        feats = conv(P["fit_c12"], c10, B2, Hf, Wf, res=c20)[0].view(npix, CF)
+        if dbg is not None:
+            dbg.update(primary=primary, secondary=secondary, fit=feats, c5=c5, pooled=pooled)
+        key = feats
+        out = feats
+        for e in P["SET"]:
+            out = block(e, out, key, False)
+        feats = new(npix, CF)
+        check(L.hands_add_rowvec_f32(ptr(out), ptr(kpe), ptr(feats), B2, NTOK, CF, stream), "add_kpe")   # model.py:88-89
+
+        # -- regressor (hand_head.py, mano_head.py:190-207) -------------------------------------------
+        def unit(u, x, H, W):
+            n = B2 * H * W
+            t0 = new(n, CF)
+            check(L.hands_bn_leaky_f32(ptr(x), ptr(u["pre"][0]), ptr(u["pre"][1]), ptr(t0), n, CF, stream), "bn_leaky")
+            t1 = conv(u["c1"], t0, B2, H, W, ACT_LEAKY_RELU)[0]
+            t2 = conv(u["c2"], t1, B2, H, W, ACT_LEAKY_RELU)[0]
+            return conv(u["c3"], t2, B2, H, W, res=x)[0]
+
+        def pool(x, H, W, mode):
+            o = new(B2, H // 2, W // 2, CF)
+            check(L.hands_pool2x2_nhwc_f32(ptr(x), ptr(o), B2, H, W, CF, mode, stream), "pool2x2")
+            return o
+
+        def hourglass(n, x, H, W):                                  # hand_head.py:217-235
+            lv = P["hg"][n - 1]
+            up1 = unit(lv[0], x, H, W)
+            low1 = unit(lv[1], pool(x, H, W, 1), H // 2, W // 2)
+            low2 = hourglass(n - 1, low1, H // 2, W // 2) if n > 1 else unit(lv[3], low1, H // 2, W // 2)
+            low3 = unit(lv[2], low2, H // 2, W // 2)
+            o = new(B2, H, W, CF)
+            check(L.hands_upsample_nearest2x_add_f32(ptr(low3), ptr(up1), ptr(o), B2, H // 2, W // 2, CF, stream), "up2x")
+            return o
+
+        if dbg is not None:
+            dbg["set"] = out
+        y = hourglass(4, feats, Hf, Wf)
+        if dbg is not None:
+            dbg["hourglass"] = y
+        y = unit(P["res"], y, Hf, Wf)
+        y = conv(P["fc"], y, B2, Hf, Wf, ACT_LEAKY_RELU)[0]
+        lat = conv(P["score"], y, B2, Hf, Wf)[0]                     # (B2,32,32,24): 21 joints + pad
+        heat = new(npix, 32)
+        check(L.hands_spatial_softmax_f32(ptr(lat), P["score"].Cout, ptr(P["betas"]), ptr(heat), 32, B2, NTOK, 21, stream),
+              "spatial_softmax")
+        if dbg is not None:
+            dbg.update(heat=heat, lat=lat)
+        hm = conv(P["hm_conv"], heat, B2, Hf, Wf)[0]
+        x = conv(P["enc_conv"], y, B2, Hf, Wf, res=hm)[0]
+        H, W = Hf, Wf
+        for i in range(4):
+            x = unit(P["enc"][2 * i], x, H, W)
+            x = unit(P["enc"][2 * i + 1], x, H, W)
+            x = pool(x, H, W, 1)
+            H, W = H // 2, W // 2
+        if dbg is not None:
+            dbg["enc"] = x
+        f = conv(P["base0"], x, B2, 1, 1, ACT_LEAKY_RELU)[0]         # x: (B2,2,2,256) read as (B2,1024)
+        f = conv(P["base2"], f, B2, 1, 1, ACT_LEAKY_RELU)[0]
+        pred = conv(P["regs"], f, B2, 1, 1)[0].view(B2, 112)
+        rot = new(B2, 16, 3, 3)
+        check(L.hands_rot6d_to_matrix_cols_f32(ptr(pred), 112, ptr(rot), B2, stream), "rot6d_cols")
+        if dbg is not None:
+            dbg["pred"] = pred
+        shape = pred[:, 96:106].contiguous()
+        cam = pred[:, 108:111].contiguous()
+        # -- MANOHead x2, grasp (model.py:103-120) ------------------------------------------------------
+        ws = {}
+
+        def buf(name, numel):
+            if name not in ws:
+                ws[name] = new(numel)
+            return ws[name]
+
+        output = run_mano_heads(L, P["mano_r"], P["mano_l"], rot, shape, cam, cam, K, float(self.img_res), bz, stream, buf)
+        gld = P["g0"].Cin
+        gin = new(B2, gld)
+        check(L.hands_grasp_input_f32(ptr(shape), 10, ptr(rot), ptr(shape), ptr(gin), B2, bz, 0, gld, stream), "grasp_in")
+        g = conv(P["g0"], gin, B2, 1, 1, ACT_RELU)[0]
+        g = conv(P["g2"], g, B2, 1, 1, ACT_RELU)[0]
+        g = conv(P["g4"], g, B2, 1, 1, ACT_RELU)[0]
+        g4 = conv(P["g6"], g, B2, 1, 1)[0].view(B2, 12)
+        grasp = xdict()
+        grasp["grasp.r"] = g4[:bz, :9].contiguous()
+        grasp["grasp.l"] = g4[bz:, :9].contiguous()
+        output.merge(grasp)
+        return output

@@ -29,7 +29,10 @@ def _is_bn(key: str) -> bool:
     if leaf_parent.startswith("bn"):
         return True
     # torchvision naming: downsample.0 = conv, downsample.1 = BN
-    return len(parts) >= 3 and parts[-3] == "downsample" and leaf_parent == "1"
+    if len(parts) >= 3 and parts[-3] == "downsample" and leaf_parent == "1":
+        return True
+    # handoccnet_light: backbone.layer0 = Sequential(conv1, bn1, ...), BasicBlock.block = Sequential(conv, bn, ..)
+    return len(parts) >= 3 and leaf_parent == "1" and parts[-3] in ("layer0", "block")
 
 
 def recipe_tensor(key: str, ref: torch.Tensor) -> torch.Tensor | None:
@@ -48,6 +51,12 @@ def recipe_tensor(key: str, ref: torch.Tensor) -> torch.Tensor | None:
         return (0.2 * torch.randn(shape, generator=g)).to(ref.dtype)
     if leaf == "pos_embedding":
         return torch.randn(shape, generator=g).to(ref.dtype)
+    if leaf in ("q_embedding", "k_embedding"):          # handoccnet FIT/SET learned 256x32x32 embeddings
+        return (0.5 * torch.randn(shape, generator=g)).to(ref.dtype)
+    if leaf == "betas":                                 # hand_regHead spatial-softmax temperatures (21,1)
+        return (1.0 + 0.2 * torch.randn(shape, generator=g)).to(ref.dtype)
+    if leaf in ("uu", "vv"):
+        return None
     if len(parts) >= 2 and parts[-2] in ("norm", "norm1", "norm2", "last_norm"):   # LayerNorm
         if leaf == "weight":
             return (1.0 + 0.1 * torch.randn(shape, generator=g)).to(ref.dtype)
@@ -79,7 +88,19 @@ def recipe_tensor(key: str, ref: torch.Tensor) -> torch.Tensor | None:
             w = 0.1 * w
         if key.endswith(("attn.proj.weight", "mlp.fc2.weight", "to_out.0.weight", "fn.net.3.weight")):
             w = 0.5 * w    # transformer residual branches (hamer_light)
-        if key.endswith(("decpose.weight", "decshape.weight", "deccam.weight")):
+        # handoccnet_light: keep FIT/SET, hourglass and encoder activations O(1-10)
+        if key.startswith("regressor.") and key.endswith(".conv3.weight"):
+            w = 0.2 * w          # residual branches of the 13 + 1 + 8 pre-activation units
+        if key.endswith(("encode_value.weight", "encoding_conv.weight", "heatmap_conv.weight")):
+            w = 0.3 * w
+        if key.endswith(("encode_query.weight", "encode_key.weight")):
+            w = 0.05 * w         # attention logits O(1-10) as in a trained net (He-scale q,k give one-hot softmax)
+        if key.endswith(("encode_query2.weight", "encode_key2.weight")):
+            w = 0.01 * w         # the FIT gate logit is a SUM over 1024 keys (transformer.py:88): keep it O(1)
+        if key.startswith(("FIT.conv", "SET.conv")):
+            w = 0.5 * w
+        if key.endswith(("decpose.weight", "decshape.weight", "deccam.weight", "pose_reg.weight",
+                         "shape_reg.weight", "cam_reg.weight")):
             w = 0.02 * w
         if key.startswith("feature_conv.0") or key.startswith("grasp_classifier.0"):
             w = 0.25 * w  # inputs are sums of O(1) feature maps (crop+glb, 49-pixel sum-pool)
@@ -90,10 +111,16 @@ def recipe_tensor(key: str, ref: torch.Tensor) -> torch.Tensor | None:
             b = 0.1 * torch.randn(shape, generator=g)   # x3 iterations: joint rotations of ~0.3 rad
         elif ".decoders.shape." in key:
             b = 0.3 * torch.randn(shape, generator=g)   # betas O(1)
-        if key.endswith("decpose.bias"):
+        if key.endswith(("decpose.bias", "pose_reg.bias")):
             b = 0.3 * torch.randn(shape, generator=g)
-        elif key.endswith("decshape.bias"):
+            if key.endswith("pose_reg.bias"):
+                # handoccnet regresses the 6D pose directly (no mean-pose init, mano_head.py:190-195):
+                # centre it on the identity so that Gram-Schmidt stays well conditioned
+                b = b + torch.tensor([1.0, 0, 0, 0, 1.0, 0]).repeat(shape[0] // 6)
+        elif key.endswith(("decshape.bias", "shape_reg.bias")):
             b = 0.5 * torch.randn(shape, generator=g)
+        elif key.endswith("cam_reg.bias"):
+            b = b + torch.tensor([1.0, 0.0, 0.0])
         if key.endswith("cam_init.4.bias"):
             b = b + torch.tensor([1.0, 0.0, 0.0])  # weak-perspective scale near 1
         return b.to(ref.dtype)

@@ -194,6 +194,63 @@ int hands_cross_attention_1q_f32(const float* q, const float* kv, float* out, in
 int hands_rot6d_to_matrix_cols_f32(const float* pose6d, int ld6, float* rotmat, int B,
                                    hands_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * handoccnet_light (LeakyReLU ResNet-50 + FPN + CBAM gate + FIT/SET attention + hourglass regressor):
+ * src/models/handoccnet_light/.  Convolutions and linear layers run on hands_conv2d_nhwc_f32
+ * (HANDS_ACT_LEAKY_RELU epilogue); all tensors NHWC, C % 4 == 0.
+ * --------------------------------------------------------------------------------------------- */
+
+/* out = F.interpolate(x (B,h,w,C) -> (H,W), bilinear, align_corners=False) + y.  backbone.py:40-42. */
+int hands_upsample_bilinear_add_f32(const float* x, const float* y, float* out, int B, int h, int w,
+                                    int H, int W, int C, hands_stream_t stream);
+
+/* 2x2 stride-2 pooling: mode 0 = AvgPool2d (backbone.py:38,62), 1 = max (hand_head.py:219,276). */
+int hands_pool2x2_nhwc_f32(const float* in, float* out, int B, int H, int W, int C, int mode,
+                           hands_stream_t stream);
+
+/* ChannelPool (cbam.py:66-68): out[pix] = [max_c x, mean_c x, 0, 0]; C must be 256. */
+int hands_channel_pool_f32(const float* x, float* out, long long npix, int C, hands_stream_t stream);
+
+/* SpatialGate tail (cbam.py:78-82): s = sigmoid(logit[pix*logit_stride]); primary = x*s;
+ * secondary = x*(1-s). */
+int hands_gate_apply_f32(const float* x, const float* logit, int logit_stride, float* primary,
+                         float* secondary, long long npix, int C, hands_stream_t stream);
+
+/* out_q = (query + q_emb[t]) + kpe[b]; out_k = (key + k_emb[t]) + kpe[b]; tokens (B,N,C), embeddings
+ * (N,C), kpe (B,C).  transformer.py:119-134. */
+int hands_add_embed2_f32(const float* query, const float* key, const float* q_emb, const float* k_emb,
+                         const float* kpe, float* out_q, float* out_k, int B, int N, int C,
+                         hands_stream_t stream);
+
+/* out[b,t,:] = x[b,t,:] + vec[b,:]   (handoccnet_light/model.py:88-89). */
+int hands_add_rowvec_f32(const float* x, const float* vec, float* out, int B, int N, int C,
+                         hands_stream_t stream);
+
+/* out[b,c] = sum_t x[b,t,c]. */
+int hands_token_sum_f32(const float* x, float* out, int B, int N, int C, hands_stream_t stream);
+
+/* out = LeakyReLU_0.01(x * scale[c] + shift[c]): eval BatchNorm (folded by the host) + activation
+ * in front of a convolution (pre-activation residual units, hand_head.py:131-133,170-172). */
+int hands_bn_leaky_f32(const float* x, const float* scale, const float* shift, float* out,
+                       long long npix, int C, hands_stream_t stream);
+
+/* out = up1 + nearest_upsample_2x(low (B,h,w,C))   (hand_head.py:228-230). */
+int hands_upsample_nearest2x_add_f32(const float* low, const float* up1, float* out, int B, int h,
+                                     int w, int C, hands_stream_t stream);
+
+/* heatmaps[b,t,j] = softmax_t(latents[b,t,j] * betas[j]) for j < J, 0 for J <= j < ld_out
+ * (hand_head.py:62-67).  Row strides ld_in / ld_out. */
+int hands_spatial_softmax_f32(const float* latents, int ld_in, const float* betas, float* heatmaps,
+                              int ld_out, int B, int N, int J, hands_stream_t stream);
+
+/* softmax((q k^T) * scale) v per (batch, head) with online softmax on fp32 MFMA; q,k,v,out (B*N,
+ * heads*64).  Optional FIT gate: output rows scaled by sigmoid((q2 . k2sum[b]) * scale), k2sum (B,
+ * heads*64) = sum over the tokens of k2; optional residual added to the output.
+ * transformer.py:71-98,146-153.  N % 128 == 0, head_dim == 64. */
+int hands_flash_attention_f32(const float* q, const float* k, const float* v, const float* q2,
+                              const float* k2sum, const float* resid, float* out, int B, int N,
+                              int heads, int head_dim, float scale, hands_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

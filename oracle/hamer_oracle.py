@@ -28,6 +28,7 @@ def kpe_embedding(inputs, prefix, sd, n_freq=4):
     """pos_emb.py:28-64: MLP(80 -> 1280 -> 1280, ReLU after both) of cat(center_enc, corner_enc)."""
     enc = torch.cat([O.pos_enc(inputs[prefix + "center_angle"], n_freq),
                      O.pos_enc(inputs[prefix + "corner_angle"], n_freq)], dim=1)
+    enc = enc.to(sd["kpe.feat_mlp.0.weight"].dtype)      # fp64 when the oracle is run as its own numeric reference
     x = F.relu(_lin(enc, sd, "kpe.feat_mlp.0"))
     return F.relu(_lin(x, sd, "kpe.feat_mlp.2"))                  # (bz, 1280); repeated over tokens
 

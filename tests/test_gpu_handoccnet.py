@@ -1,0 +1,145 @@
+"""GPU parity tests of the handoccnet_light path through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import hands_amd
+from hands_amd import _lib
+from hands_amd._lib import check, ptr
+from hands_amd.weights import synthetic_inputs
+from oracle import handoccnet_oracle as HO
+from oracle import hands_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def test_flash_attention_vs_oracle():
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(0)
+    B, N, heads, D = 2, 1024, 4, 64
+    C = heads * D
+    q, k, v, q2, k2, res = (torch.randn(B, N, C, generator=g) for _ in range(6))
+    q, k = 2.0 * q, 1.5 * k        # wide logits: exercises the online-softmax rescale across key tiles
+    k2 = 0.05 * k2
+    ref_gate = HO.attention(q.double(), k.double(), v.double(), q2.double(), k2.double(), heads, True)
+    ref_plain = res.double() + HO.attention(q.double(), k.double(), v.double(), None, None, heads, False)
+    d = [t.to(DEV) for t in (q, k, v, q2, k2, res)]
+    k2sum = torch.empty(B, C, device=DEV)
+    check(L.hands_token_sum_f32(ptr(d[4]), ptr(k2sum), B, N, C, _stream()))
+    assert (k2sum.cpu().double() - k2.double().sum(1)).abs().max().item() < 1e-4
+    out = torch.full((B, N, C), float("nan"), device=DEV)
+    check(L.hands_flash_attention_f32(ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(k2sum), None, ptr(out), B, N, heads,
+                                      D, float(D ** -0.5), _stream()))
+    assert (out.cpu().double() - ref_gate).abs().max().item() < 2e-5
+    check(L.hands_flash_attention_f32(ptr(d[0]), ptr(d[1]), ptr(d[2]), None, None, ptr(d[5]), ptr(out), B, N, heads, D,
+                                      float(D ** -0.5), _stream()))
+    assert (out.cpu().double() - ref_plain).abs().max().item() < 2e-5
+
+
+def test_fpn_and_pool_kernels():
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(2, 256, 8, 8, generator=g), torch.randn(2, 256, 16, 16, generator=g)
+    d = [_nhwc(x).to(DEV), _nhwc(y).to(DEV)]
+    out = torch.empty(2, 16, 16, 256, device=DEV)
+    check(L.hands_upsample_bilinear_add_f32(ptr(d[0]), ptr(d[1]), ptr(out), 2, 8, 8, 16, 16, 256, _stream()))
+    ref = F.interpolate(x, size=(16, 16), mode="bilinear", align_corners=False) + y
+    assert (out.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 2e-6
+    for mode, fn in ((0, F.avg_pool2d), (1, F.max_pool2d)):
+        o = torch.empty(2, 8, 8, 256, device=DEV)
+        check(L.hands_pool2x2_nhwc_f32(ptr(d[1]), ptr(o), 2, 16, 16, 256, mode, _stream()))
+        assert (o.cpu().permute(0, 3, 1, 2) - fn(y, 2, 2)).abs().max().item() < 1e-6
+    # nearest upsample + add
+    low, up1 = torch.randn(2, 256, 4, 4, generator=g), torch.randn(2, 256, 8, 8, generator=g)
+    dd = [_nhwc(low).to(DEV), _nhwc(up1).to(DEV)]
+    o = torch.empty(2, 8, 8, 256, device=DEV)
+    check(L.hands_upsample_nearest2x_add_f32(ptr(dd[0]), ptr(dd[1]), ptr(o), 2, 4, 4, 256, _stream()))
+    assert torch.equal(o.cpu().permute(0, 3, 1, 2), up1 + F.interpolate(low, scale_factor=2))
+
+
+def test_gate_embed_bn_softmax_kernels():
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(2)
+    p2 = torch.randn(2, 256, 32, 32, generator=g)
+    xd = _nhwc(p2).to(DEV)
+    comp = torch.empty(2 * 1024, 4, device=DEV)
+    check(L.hands_channel_pool_f32(ptr(xd), ptr(comp), 2048, 256, _stream()))
+    c = comp.cpu().view(2, 32, 32, 4)
+    assert torch.equal(c[..., 0], p2.max(1)[0]) and (c[..., 1] - p2.mean(1)).abs().max().item() < 1e-6
+    logit = torch.randn(2048, 4, generator=g)
+    ld = logit.to(DEV)
+    pr, se = torch.empty(2048, 256, device=DEV), torch.empty(2048, 256, device=DEV)
+    check(L.hands_gate_apply_f32(ptr(xd), ptr(ld), 4, ptr(pr), ptr(se), 2048, 256, _stream()))
+    s = torch.sigmoid(logit[:, 0]).view(2, 1, 32, 32)
+    assert (pr.cpu().view(2, 32, 32, 256).permute(0, 3, 1, 2) - p2 * s).abs().max().item() < 1e-6
+    assert (se.cpu().view(2, 32, 32, 256).permute(0, 3, 1, 2) - p2 * (1 - s)).abs().max().item() < 1e-6
+    # add_embed2 / add_rowvec
+    q, k = torch.randn(2, 1024, 256, generator=g), torch.randn(2, 1024, 256, generator=g)
+    qe, ke, kp = torch.randn(1024, 256, generator=g), torch.randn(1024, 256, generator=g), torch.randn(2, 256, generator=g)
+    d = [t.to(DEV) for t in (q, k, qe, ke, kp)]
+    oq, ok = torch.empty(2, 1024, 256, device=DEV), torch.empty(2, 1024, 256, device=DEV)
+    check(L.hands_add_embed2_f32(*[ptr(t) for t in d], ptr(oq), ptr(ok), 2, 1024, 256, _stream()))
+    assert torch.equal(oq.cpu(), (q + qe) + kp[:, None]) and torch.equal(ok.cpu(), (k + ke) + kp[:, None])
+    check(L.hands_add_rowvec_f32(ptr(d[0]), ptr(d[4]), ptr(oq), 2, 1024, 256, _stream()))
+    assert torch.equal(oq.cpu(), q + kp[:, None])
+    # bn + leaky
+    sc, sh = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    dd = [sc.to(DEV), sh.to(DEV)]
+    check(L.hands_bn_leaky_f32(ptr(d[0]), ptr(dd[0]), ptr(dd[1]), ptr(ok), 2048, 256, _stream()))
+    assert (ok.cpu() - F.leaky_relu(q * sc + sh, 0.01)).abs().max().item() < 1e-6
+    # spatial softmax
+    lat = 3 * torch.randn(2, 1024, 24, generator=g)
+    betas = 1 + 0.2 * torch.randn(21, generator=g)
+    dl, db = lat.to(DEV), betas.to(DEV)
+    heat = torch.full((2, 1024, 32), float("nan"), device=DEV)
+    check(L.hands_spatial_softmax_f32(ptr(dl), 24, ptr(db), ptr(heat), 32, 2, 1024, 21, _stream()))
+    ref = (lat[:, :, :21] * betas).double().softmax(dim=1)      # products in fp32 like the kernel, softmax in fp64
+    h = heat.cpu()
+    assert (h[:, :, :21].double() - ref).abs().max().item() < 5e-6 * ref.max().item() + 1e-7
+    assert torch.all(h[:, :, 21:] == 0)
+
+
+@pytest.fixture(scope="module")
+def hon_gpu():
+    return hands_amd.apply_recipe(hands_amd.HandOccNet()).eval().to(DEV)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_handoccnet_forward_vs_golden(golden_dir, hon_gpu, seed):
+    d = np.load(os.path.join(golden_dir, f"handoccnet_light_bz2_seed{seed}.npz"))
+    inputs, meta_info = synthetic_inputs(2, seed, device=DEV)
+    out = hon_gpu(inputs, meta_info)
+    torch.cuda.synchronize()
+    keys = [k[4:] for k in d.files if k.startswith("out/")]
+    assert sorted(out.keys()) == sorted(keys) and len(out) == 22
+    for k in keys:
+        ref, got = d["out/" + k], out[k].cpu().numpy()
+        assert got.shape == ref.shape and out[k].is_contiguous(), k
+        tol = 5e-3 if k.startswith("grasp") else 2e-4
+        np.testing.assert_allclose(got, ref, rtol=tol, atol=tol, err_msg=k)
+    for hn in "rl":
+        verr = np.abs(out[f"mano.vertices.{hn}"].cpu().numpy() - d[f"out/mano.vertices.{hn}"]).max()
+        mp = O.mpjpe_ra_mm(out[f"mano.joints3d.{hn}"].cpu(), torch.from_numpy(d[f"out/mano.joints3d.{hn}"]))
+        print(f"handoccnet seed {seed} hand {hn}: max vertex err {verr:.3e} m, MPJPE {mp:.3e} mm")
+        assert verr < 1e-6 and mp < 1e-3, (verr, mp)
+
+
+def test_handoccnet_batch_independence(hon_gpu):
+    inputs, meta_info = synthetic_inputs(5, 3, device=DEV)
+    big = {k: v.clone() for k, v in hon_gpu(inputs, meta_info).items()}
+    small = hon_gpu({k: v[:2].contiguous() for k, v in inputs.items()},
+                    {k: v[:2].contiguous() for k, v in meta_info.items()})
+    for k in small:
+        assert torch.equal(big[k][:2], small[k]), k
