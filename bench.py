@@ -77,10 +77,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # HANDS_BENCH_SHARE_GPU=1 + HANDS_BENCH_BACKEND=gloo: dry-run of the N>1 code path on a 1-GPU box
+    # (every rank on cuda:0, gloo collectives); never set by the driver.
+    share = os.environ.get("HANDS_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("HANDS_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import hands_amd
     from hands_amd.dist import gather_predictions
@@ -104,6 +112,9 @@ def main():
 
     def step():
         out = model(inputs, meta)
+        if world > 1 and backend != "nccl":      # dry-run only: gloo gathers host tensors
+            torch.cuda.synchronize(dev)
+            return gather_predictions({k: v.cpu() for k, v in out.items()})
         return gather_predictions(out) if world > 1 else out
 
     for _ in range(args.warmup):
@@ -115,6 +126,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    cpu_coll = world > 1 and backend != "nccl"
+
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -122,7 +135,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend != "nccl" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
