@@ -198,51 +198,55 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   COMPUTE_STEP((nk - 1) & 1);
 #undef COMPUTE_STEP
 
-  // ---- epilogue: D row = channel = 8*q + 4*(lane>>5) + e, D col = pixel = lane&31 ---------------
-  // All loads (bias, residual) use clamped, always-valid addresses and are issued as a batch per
-  // 32x32 block; only the stores are predicated.
+  // ---- epilogue -------------------------------------------------------------------------------------
+  // D row = channel = 8*q + 4*(lane>>5) + e, D col = pixel = lane&31.  Each wave transposes its
+  // 32-pixel x 64-channel half tile through its own slice of the (now idle) staging LDS so that the
+  // residual loads and the output stores run 256 B contiguous per pixel row (16 lanes x 16 B) instead
+  // of 32 B: the expand convolutions of layer1/layer2 are HBM-bound and store-transaction bound.
+  __syncthreads();                                  // every wave is done reading the k-loop tiles
+  constexpr int EROW = 68;                          // 64 channels + 4 pad floats (17 slots: odd)
+  float* sE = lds + wave * (32 * EROW);
   const int half = lane >> 5;
-  const int nb = n0 + wn * 64 + half * 4;
-  float4 bv[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const float4*>(a.bias + nb + i * 32 + q * 8);
+  const int c4 = lane & 15;                         // this lane's 4-channel group in the read-back
+  const int n_lane = n0 + wn * 64 + c4 * 4;
+  const bool n_ok = n_lane < a.N;
+  const float4 bv = *reinterpret_cast<const float4*>(a.bias + n_lane);
   const bool has_res = a.res != nullptr;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int m = m0 + wm * 64 + j * 32 + (lane & 31);
-    const bool m_ok = m < a.M;
-    const int mc = m_ok ? m : a.M - 1;
-    float* orow = a.out + (size_t)mc * a.out_ps;
-    const float* rrow = has_res ? a.res + (size_t)mc * a.res_ps : a.bias;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float4 rv[4];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = nb + i * 32 + q * 8;
-        rv[q] = has_res ? *reinterpret_cast<const float4*>(rrow + (n < a.N ? n : 0))
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(sE + (lane & 31) * EROW + i * 32 + q * 8 + half * 4) =
+            make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+    const int mbase = m0 + wm * 64 + j * 32 + (lane >> 4);
+    float4 rv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int m = mbase + 4 * r;
+      const int mc = m < a.M ? m : a.M - 1;
+      rv[r] = has_res ? *reinterpret_cast<const float4*>(a.res + (size_t)mc * a.res_ps + (n_ok ? n_lane : 0))
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int m = mbase + 4 * r;
+      const float4 t = *reinterpret_cast<const float4*>(sE + ((lane >> 4) + 4 * r) * EROW + c4 * 4);
+      float4 v;
+      v.x = t.x + bv.x + rv[r].x;
+      v.y = t.y + bv.y + rv[r].y;
+      v.z = t.z + bv.z + rv[r].z;
+      v.w = t.w + bv.w + rv[r].w;
+      if (a.relu == HANDS_ACT_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      } else if (a.relu == HANDS_ACT_GELU) {
+        v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+      } else if (a.relu == HANDS_ACT_LEAKY_RELU) {
+        v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;
+        v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = nb + i * 32 + q * 8;
-        float4 v;
-        v.x = acc[i][j][q * 4 + 0] + bv[i][q].x + rv[q].x;
-        v.y = acc[i][j][q * 4 + 1] + bv[i][q].y + rv[q].y;
-        v.z = acc[i][j][q * 4 + 2] + bv[i][q].z + rv[q].z;
-        v.w = acc[i][j][q * 4 + 3] + bv[i][q].w + rv[q].w;
-        if (a.relu == HANDS_ACT_RELU) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        } else if (a.relu == HANDS_ACT_GELU) {
-          v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
-        } else if (a.relu == HANDS_ACT_LEAKY_RELU) {
-          v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;
-          v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;
-        }
-        if (m_ok && n < a.N) *reinterpret_cast<float4*>(orow + n) = v;
-      }
+      if (m < a.M && n_ok) *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ps + n_lane) = v;
     }
   }
 #undef LOAD_TILES
