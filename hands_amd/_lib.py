@@ -33,6 +33,17 @@ class ManoOut(C.Structure):
                 ("j3d_cam", C.c_void_p), ("j2d_norm", C.c_void_p), ("cam_t", C.c_void_p)]
 
 
+class EvalIn(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "pred_j3d_r", "pred_j3d_l", "gt_j3d_r", "gt_j3d_l", "pred_j2d_r", "pred_j2d_l", "gt_j2d_r", "gt_j2d_l",
+        "is_valid", "right_valid", "left_valid", "joints_valid_r", "joints_valid_l")]
+
+
+class EvalOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "mpjpe_ra_h", "mpjpe_pa_ra_r", "mpjpe_pa_ra_l", "mpjpe_pa_ra_h", "mrrpe_rl", "pix_err_r", "pix_err_l")]
+
+
 # name -> argtypes; every function returns int (0 = ok) except the two noted below
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
@@ -65,6 +76,7 @@ SIGNATURES = {
     "hands_upsample_nearest2x_add_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
     "hands_spatial_softmax_f32": [_P, _I, _P, _P, _I, _I, _I, _I, _P],
     "hands_flash_attention_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "hands_eval_metrics_f32": [C.POINTER(EvalIn), C.POINTER(EvalOut), _I, _P],
 }
 EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string")
 

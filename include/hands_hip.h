@@ -251,6 +251,28 @@ int hands_flash_attention_f32(const float* q, const float* k, const float* v, co
                               const float* k2sum, const float* resid, float* out, int B, int N,
                               int heads, int head_dim, float scale, hands_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Evaluation metrics on the (gathered) predictions, on device: src/utils/eval_modules.py:97-134
+ * (mpjpe/ra/h), :136-219,320-343 (mpjpe/pa/ra/{r,l,h}, Procrustes with a 3x3 SVD per hand),
+ * :386-407 (mrrpe/r/l), :410-428 (pix_err/{r,l}); common/metrics.py:23-55.  Millimetres / pixels,
+ * NaN conventions as the reference (invalid hand -> NaN, except the PA error which it multiplies
+ * by the validity flag).  All arrays fp32: joints (B,21,3), 2-D joints (B,21,2) in pixels,
+ * per-sample flags (B), per-joint flags (B,21).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct hands_eval_in {
+  const float *pred_j3d_r, *pred_j3d_l, *gt_j3d_r, *gt_j3d_l;
+  const float *pred_j2d_r, *pred_j2d_l, *gt_j2d_r, *gt_j2d_l;
+  const float *is_valid, *right_valid, *left_valid, *joints_valid_r, *joints_valid_l;
+} hands_eval_in;
+
+typedef struct hands_eval_out {
+  float *mpjpe_ra_h, *mpjpe_pa_ra_r, *mpjpe_pa_ra_l, *mpjpe_pa_ra_h, *mrrpe_rl; /* (B) each */
+  float *pix_err_r, *pix_err_l;                                                  /* (B,21) */
+} hands_eval_out;
+
+int hands_eval_metrics_f32(const hands_eval_in* in, const hands_eval_out* out, int B,
+                           hands_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -196,3 +196,17 @@ def test_shard_and_pack_roundtrip():
     flat, layout = pack_predictions(out)
     back = unpack_predictions(flat, layout)
     assert flat.shape == (3, 778 * 3 + 144 + 9) and all(torch.equal(back[k], out[k]) for k in out)
+
+
+def test_load_reference_style_checkpoint(tmp_path, recipe_model):
+    from hands_amd.checkpoint import load_reference_checkpoint
+    sd = {"model." + k: v.clone() for k, v in recipe_model.state_dict().items()}
+    sd["mano_r.shapedirs"] = torch.zeros(778, 3, 10)            # wrapper-level buffers are ignored
+    sd["model.mano_r.mano.unknown_smplx_buffer"] = torch.zeros(3)
+    path = str(tmp_path / "last.ckpt")
+    torch.save({"state_dict": sd, "epoch": 3}, path)
+    m = hands_amd.HandsLight()
+    rep = load_reference_checkpoint(m, path)
+    assert rep.missing_keys == [] and rep.unexpected_keys == ["mano_r.mano.unknown_smplx_buffer"]
+    for k, v in recipe_model.state_dict().items():
+        assert torch.equal(m.state_dict()[k], v), k
