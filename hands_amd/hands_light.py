@@ -465,21 +465,35 @@ class HandsLight(nn.Module):
         self._conv(L, P["fc7"], f3, B2, 1, 1, state, True, stream, out_ps=ld)
 
         # -- HandHMR x2 (hand_hmr.py:73-92, hmr_layer.py:67-86) ----------------------------------
-        h512a, h512b = buf("h512a", bz * 512), buf("h512b", bz * 512)
-        x1, x2 = buf("x1024a", bz * 1024), buf("x1024b", bz * 1024)
         caminit4 = buf("caminit4", B2 * 4)
+        # the two heads are independent chains of latency-bound M = bz GEMMs: run them side by side
+        evh = torch.cuda.Event()
+        evh.record(main)
+        joins = []
         for side, hp in ((0, P["head_r"]), (1, P["head_l"])):
+            hs = main if (side == 1 or not HandsLight.overlap_trunks) else self._side_stream(dev, "side_head")
+            if hs is not main:
+                hs.wait_event(evh)
+            sh = hs.cuda_stream
+            h512a, h512b = buf(f"h512a{side}", bz * 512), buf(f"h512b{side}", bz * 512)
+            x1, x2 = buf(f"x1024a{side}", bz * 1024), buf(f"x1024b{side}", bz * 1024)
             so = side * bz * ld
-            self._conv(L, hp["ci0"], state, bz, 1, 1, h512a, True, stream, in_ps=ld, x_off=so)
-            self._conv(L, hp["ci2"], h512a, bz, 1, 1, h512b, True, stream)
-            self._conv(L, hp["ci4"], h512b, bz, 1, 1, caminit4, False, stream, out_off=side * bz * 4)
-            check(L.hands_hmr_init_f32(ptr(state, so), ptr(caminit4, side * bz * 4), bz, ld, F, stream),
+            self._conv(L, hp["ci0"], state, bz, 1, 1, h512a, True, sh, in_ps=ld, x_off=so)
+            self._conv(L, hp["ci2"], h512a, bz, 1, 1, h512b, True, sh)
+            self._conv(L, hp["ci4"], h512b, bz, 1, 1, caminit4, False, sh, out_off=side * bz * 4)
+            check(L.hands_hmr_init_f32(ptr(state, so), ptr(caminit4, side * bz * 4), bz, ld, F, sh),
                   "hmr_init")
             for _ in range(3):
-                self._conv(L, hp["r0"], state, bz, 1, 1, x1, True, stream, in_ps=ld, x_off=so)
-                self._conv(L, hp["r3"], x1, bz, 1, 1, x2, True, stream)
-                self._conv(L, hp["dec"], x2, bz, 1, 1, state, False, stream, res=state, out_ps=ld,
+                self._conv(L, hp["r0"], state, bz, 1, 1, x1, True, sh, in_ps=ld, x_off=so)
+                self._conv(L, hp["r3"], x1, bz, 1, 1, x2, True, sh)
+                self._conv(L, hp["dec"], x2, bz, 1, 1, state, False, sh, res=state, out_ps=ld,
                            res_ps=ld, out_off=so + F, res_off=so + F)
+            if hs is not main:
+                ev = torch.cuda.Event()
+                ev.record(hs)
+                joins.append(ev)
+        for ev in joins:
+            main.wait_event(ev)
         rotmat = buf("rotmat", B2 * 144)
         check(L.hands_rot6d_to_matrix_f32(ptr(state, F), ld, ptr(rotmat), B2, stream), "rot6d")
         st = state[: B2 * ld].view(B2, ld)
