@@ -77,6 +77,9 @@ SIGNATURES = {
     "hands_spatial_softmax_f32": [_P, _I, _P, _P, _I, _I, _I, _I, _P],
     "hands_flash_attention_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "hands_eval_metrics_f32": [C.POINTER(EvalIn), C.POINTER(EvalOut), _I, _P],
+    "hands_mano_pose_aa_f32": [C.POINTER(ManoConsts), _P, _P, _I, _P, _I, _P, _P, _I, _P],
+    "hands_gt_targets_f32": [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _P],
+    "hands_unnormalize_kp2d_f32": [_P, _P, C.c_longlong, _F, _P],
 }
 EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string")
 

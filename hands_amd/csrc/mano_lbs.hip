@@ -30,6 +30,7 @@ constexpr int HANDS_PER_BLOCK = 4;
 __device__ __forceinline__ int parent_of(int j) { return j == 0 ? -1 : ((j - 1) % 3 == 0 ? 0 : j - 1); }
 __device__ __forceinline__ int depth_of(int j) { return j == 0 ? 0 : (j - 1) % 3 + 1; }
 
+template <bool AA_INPUT>
 __global__ void __launch_bounds__(64) mano_pose_kernel(hands_mano_consts c, const float* __restrict__ rotmat,
                                                        const float* __restrict__ betas, int ld_betas,
                                                        float* __restrict__ blend_in, int ld_blend,
@@ -44,7 +45,12 @@ __global__ void __launch_bounds__(64) mano_pose_kernel(hands_mano_consts c, cons
 
   if (live) {
     float aa[3], R[9];
-    hands::matrix_to_axis_angle(rotmat + ((long long)b * NJ + j) * 9, aa);
+    if constexpr (AA_INPUT) {        // ground-truth MANO parameters are axis-angle already (process_arctic.py:16-21)
+      const float* src = rotmat + ((long long)b * NJ + j) * 3;
+      aa[0] = src[0]; aa[1] = src[1]; aa[2] = src[2];
+    } else {
+      hands::matrix_to_axis_angle(rotmat + ((long long)b * NJ + j) * 9, aa);
+    }
     aa[0] += c.pose_mean[3 * j + 0];
     aa[1] += c.pose_mean[3 * j + 1];
     aa[2] += c.pose_mean[3 * j + 2];
@@ -199,8 +205,18 @@ int hands_mano_pose_f32(const hands_mano_consts* c, const float* rotmat, const f
   if (!c || !c->pose_mean || !c->J_template || !c->J_shapedirs || !rotmat || !betas || !blend_in ||
       !A || !joints16 || B <= 0 || ld_blend < 145 || ld_betas < 10)
     return HANDS_EINVAL;
-  hipLaunchKernelGGL(mano_pose_kernel, dim3((B + HANDS_PER_BLOCK - 1) / HANDS_PER_BLOCK), dim3(64), 0,
+  hipLaunchKernelGGL(mano_pose_kernel<false>, dim3((B + HANDS_PER_BLOCK - 1) / HANDS_PER_BLOCK), dim3(64), 0,
                      (hipStream_t)stream, *c, rotmat, betas, ld_betas, blend_in, ld_blend, A, joints16, B);
+  HANDS_LAUNCH_CHECK();
+}
+
+int hands_mano_pose_aa_f32(const hands_mano_consts* c, const float* axis_angle, const float* betas, int ld_betas,
+                           float* blend_in, int ld_blend, float* A, float* joints16, int B, hands_stream_t stream) {
+  if (!c || !c->pose_mean || !c->J_template || !c->J_shapedirs || !axis_angle || !betas || !blend_in || !A ||
+      !joints16 || B <= 0 || ld_blend < 145 || ld_betas < 10)
+    return HANDS_EINVAL;
+  hipLaunchKernelGGL(mano_pose_kernel<true>, dim3((B + HANDS_PER_BLOCK - 1) / HANDS_PER_BLOCK), dim3(64), 0,
+                     (hipStream_t)stream, *c, axis_angle, betas, ld_betas, blend_in, ld_blend, A, joints16, B);
   HANDS_LAUNCH_CHECK();
 }
 

@@ -154,7 +154,57 @@ __global__ void eval_metrics_kernel(hands_eval_in in, hands_eval_out out, int B)
   }
 }
 
+// process_data_light (src/callbacks/process/process_arctic.py:41-73): camera-space targets from the
+// canonical GT MANO output and the annotated camera-space joints.
+__global__ void gt_targets_kernel(const float* __restrict__ joints, const float* __restrict__ verts,
+                                  const float* __restrict__ j3d_full, const float* __restrict__ Kmat, float img_res,
+                                  float* __restrict__ v3d_cam, float* __restrict__ cam_t, float* __restrict__ cam_t_wp,
+                                  int B, int NV) {
+  __shared__ float tr[3];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* jc = joints + (long long)b * NJ * 3;
+  const float* jf = j3d_full + (long long)b * NJ * 3;
+  if (tid < 3) {
+    float s = 0.f;                                     // Tr0 = (j3d.full - joints).mean(dim=1)
+    for (int j = 0; j < NJ; ++j) s += jf[3 * j + tid] - jc[3 * j + tid];
+    tr[tid] = s / (float)NJ;
+    cam_t[b * 3 + tid] = jf[tid] - jc[tid];            // root_cam - root_cano
+  }
+  if (tid == 0) {
+    const float f = (Kmat[b * 9 + 0] + Kmat[b * 9 + 4]) / 2.0f;
+    const float tz = jf[2] - jc[2];
+    cam_t_wp[b * 3 + 0] = 2.0f * f / (img_res * tz + 1e-9f);    // camera.py:10-29
+    cam_t_wp[b * 3 + 1] = jf[0] - jc[0];
+    cam_t_wp[b * 3 + 2] = jf[1] - jc[1];
+  }
+  __syncthreads();
+  const float* v = verts + (long long)b * NV * 3;
+  float* o = v3d_cam + (long long)b * NV * 3;
+  for (int i = tid; i < NV * 3; i += blockDim.x) o[i] = v[i] + tr[i % 3];
+}
+
+// unormalize_kp2d (common/data_utils.py:368-373): 0.5 * res * (x + 1)
+__global__ void unnormalize_kernel(const float* __restrict__ x, float* __restrict__ out, long long n, float img_res) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = 0.5f * img_res * (x[i] + 1.0f);
+}
+
 }  // namespace
+
+extern "C" int hands_gt_targets_f32(const float* joints, const float* verts, const float* j3d_full, const float* K,
+                                    float img_res, float* v3d_cam, float* cam_t, float* cam_t_wp, int B, int NV,
+                                    hands_stream_t stream) {
+  if (!joints || !verts || !j3d_full || !K || !v3d_cam || !cam_t || !cam_t_wp || B <= 0 || NV <= 0) return HANDS_EINVAL;
+  hipLaunchKernelGGL(gt_targets_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, joints, verts, j3d_full, K, img_res,
+                     v3d_cam, cam_t, cam_t_wp, B, NV);
+  HANDS_LAUNCH_CHECK();
+}
+
+extern "C" int hands_unnormalize_kp2d_f32(const float* x, float* out, long long n, float img_res, hands_stream_t stream) {
+  if (!x || !out || n <= 0) return HANDS_EINVAL;
+  hipLaunchKernelGGL(unnormalize_kernel, dim3(hands_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, n, img_res);
+  HANDS_LAUNCH_CHECK();
+}
 
 extern "C" int hands_eval_metrics_f32(const hands_eval_in* in, const hands_eval_out* out, int B, hands_stream_t stream) {
   if (!in || !out || B <= 0) return HANDS_EINVAL;

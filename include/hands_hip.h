@@ -273,6 +273,21 @@ typedef struct hands_eval_out {
 int hands_eval_metrics_f32(const hands_eval_in* in, const hands_eval_out* out, int B,
                            hands_stream_t stream);
 
+/* GT preprocessing of the wrapper's test mode (src/callbacks/process/process_arctic.py:4-75):
+ *   hands_mano_pose_aa_f32   = hands_mano_pose_f32 for AXIS-ANGLE input (B,48) (GT MANO parameters);
+ *   hands_gt_targets_f32     : Tr0 = mean_j(j3d_full - joints); v3d_cam = verts + Tr0;
+ *                              cam_t = j3d_full[0] - joints[0];
+ *                              cam_t_wp = [2 f / (res * cam_t.z + 1e-9), cam_t.x, cam_t.y]  (common/camera.py:10-29);
+ *   hands_unnormalize_kp2d_f32: 0.5 * res * (x + 1)  (common/data_utils.py:368-373, generic/wrapper.py:118-134). */
+int hands_mano_pose_aa_f32(const hands_mano_consts* c, const float* axis_angle, const float* betas,
+                           int ld_betas, float* blend_in, int ld_blend, float* A, float* joints16,
+                           int B, hands_stream_t stream);
+int hands_gt_targets_f32(const float* joints, const float* verts, const float* j3d_full, const float* K,
+                         float img_res, float* v3d_cam, float* cam_t, float* cam_t_wp, int B, int NV,
+                         hands_stream_t stream);
+int hands_unnormalize_kp2d_f32(const float* x, float* out, long long n, float img_res,
+                               hands_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

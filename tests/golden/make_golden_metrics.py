@@ -66,3 +66,33 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def make_process_data():
+    """tests/golden/process_data.npz: the REAL process_data_light (src/callbacks/process/process_arctic.py:4-75)
+    with the MANO layers stubbed by oracle.mano_lbs on the synthetic asset (a9, flagged)."""
+    import smplx  # the stub installed by _ref_shims
+    from src.callbacks.process.process_arctic import process_data_light
+    from _ref_shims import Args
+    g = torch.Generator().manual_seed(5)
+    B = 6
+    targets = {}
+    for h in "rl":
+        targets[f"mano.pose.{h}"] = 0.4 * torch.randn(B, 48, generator=g)
+        targets[f"mano.beta.{h}"] = torch.randn(B, 10, generator=g)
+        targets[f"mano.j3d.full.{h}"] = 0.1 * torch.randn(B, 21, 3, generator=g) + torch.tensor([0.05, -0.02, 0.6])
+    K = torch.tensor([[1000.0, 0, 112], [0, 1000.0, 112], [0, 0, 1]])[None].repeat(B, 1, 1)
+    K[:, 0, 0] += 30 * torch.randn(B, generator=g)
+    models = {"mano_r": smplx.MANO("", is_rhand=True), "mano_l": smplx.MANO("", is_rhand=False)}
+    tin = {k: v.clone() for k, v in targets.items()}
+    _, tout, _ = process_data_light(models, {}, targets, {"intrinsics": K}, "test", Args(img_res=224))
+    rec = {"in/" + k: v.numpy() for k, v in tin.items()}
+    rec["in/intrinsics"] = K.numpy()
+    rec.update({"out/" + k: v.numpy() for k, v in tout.items() if k not in tin})
+    rec["meta"] = np.array(json.dumps(dict(META, what="process_arctic.py:4-75 process_data_light")))
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "process_data.npz"), **rec)
+    print("process_data keys:", sorted(k for k in rec if k.startswith("out/")))
+
+
+if __name__ == "__main__":
+    make_process_data()

@@ -1,0 +1,66 @@
+"""Wrapper test-mode shell: GT preprocessing oracle vs the reference's own
+process_data_light (CPU); device kernels vs oracle and the end-to-end test-mode contract (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hands_amd.mano import synthetic_mano_asset
+from oracle import wrapper_oracle as WO
+
+
+def _load(golden_dir):
+    d = np.load(os.path.join(golden_dir, "process_data.npz"))
+    tin = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("in/")}
+    ref = {k[4:]: d[k] for k in d.files if k.startswith("out/")}
+    return tin, ref
+
+
+def test_process_data_oracle_matches_reference(golden_dir):
+    tin, ref = _load(golden_dir)
+    K = tin.pop("intrinsics")
+    out = WO.process_data_light(tin, K, synthetic_mano_asset(True), synthetic_mano_asset(False))
+    assert set(ref) == set(out)
+    for k, v in ref.items():
+        np.testing.assert_allclose(out[k].numpy(), v, rtol=1e-6, atol=1e-7, err_msg=k)
+    x = torch.randn(3, 21, 2)
+    assert torch.equal(WO.unnormalize_kp2d(x, 224), 0.5 * 224 * (x + 1))
+
+
+@pytest.mark.gpu
+def test_wrapper_test_mode_on_device(golden_dir, recipe_model):
+    import copy
+    from hands_amd.weights import synthetic_inputs
+    from hands_amd.wrapper import HandsWrapper
+    from hands_amd.xdict import xdict
+    tin, ref = _load(golden_dir)
+    w = HandsWrapper(model=copy.deepcopy(recipe_model).to("cuda"))
+    K = tin.pop("intrinsics")
+    t = w.process_data(xdict({k: v.cuda() for k, v in tin.items()}), {"intrinsics": K.cuda()})
+    for k, v in ref.items():
+        got = t[k].cpu().numpy()
+        tol = 2e-6 if "cam_t.wp" not in k else 2e-5      # s = 2f/(res*tz): relative
+        np.testing.assert_allclose(got, v, rtol=tol, atol=2e-6, err_msg=k)
+    # full test-mode pass: predictions vs self-consistent targets
+    B = K.shape[0]
+    inputs, meta = synthetic_inputs(B, 4, device="cuda")
+    meta["intrinsics"] = K.cuda()
+    meta["imgname"] = [f"{i}.jpg" for i in range(B)]
+    targets = {k: v.cuda() for k, v in tin.items()}
+    g = torch.Generator().manual_seed(1)
+    for h in "rl":
+        targets[f"mano.j2d.norm.{h}"] = (0.5 * torch.randn(B, 21, 2, generator=g)).cuda()
+        targets[f"joints_valid_{h}"] = torch.ones(B, 21).cuda()
+    targets.update(is_valid=torch.ones(B).cuda(), right_valid=torch.ones(B).cuda(), left_valid=torch.tensor([1.0, 0, 1, 1, 1, 1]).cuda())
+    out_dict, loss = w.forward(inputs, targets, meta, "test")
+    assert loss == {} and out_dict["imgname"] == meta["imgname"]
+    for k in ("metric.mpjpe/ra/h", "metric.mpjpe/pa/ra/h", "metric.mrrpe/r/l", "metric.pix_err/h"):
+        assert k in out_dict and out_dict[k].device.type == "cpu" and out_dict[k].shape[0] == B
+    assert torch.isnan(out_dict["metric.mrrpe/r/l"][1]) and torch.isfinite(out_dict["metric.mpjpe/ra/h"]).all()
+    ex = w.forward(inputs, targets, meta, "extract")
+    assert "pred.mano.j2d.r" in ex and "targets.mano.v3d.cam.l" in ex and ex["pred.mano.vertices.r"].device.type == "cpu"
+    pr = ex["pred.mano.j2d.norm.r"]
+    assert torch.allclose(ex["pred.mano.j2d.r"], 0.5 * 224 * (pr + 1), atol=1e-4)
+    with pytest.raises(NotImplementedError):
+        w.forward(inputs, targets, meta, "train")
