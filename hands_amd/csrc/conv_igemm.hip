@@ -28,6 +28,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // nn.GELU() (exact, erf form): x * 0.5 * (1 + erf(x / sqrt(2)))
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+__device__ __forceinline__ float4 apply_act(float4 v, int act) {
+  if (act == HANDS_ACT_RELU) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  } else if (act == HANDS_ACT_GELU) {
+    v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+  } else if (act == HANDS_ACT_LEAKY_RELU) {
+    v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;
+    v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;
+  }
+  return v;
+}
+
 __device__ __forceinline__ float f4elem(const float4& v, int t) {
   return t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w));
 }
@@ -46,6 +58,9 @@ struct ConvArgs {
   int in_ps, out_ps, res_ps;
   int relu;
   int nblk_m, nblk_n;
+  int ksplit;         // > 1: deterministic split-K, grid = tiles * ksplit, raw partial sums to `partial`
+  float* partial;     // [ksplit][M][part_ps]
+  int part_ps;
 };
 
 // XCD-aware block remap: blocks are dispatched round-robin over the 8 XCDs (private L2 each);
@@ -75,7 +90,9 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   const int wm = wave / WAVES_N;            // wave row (pixels)
   const int wn = wave % WAVES_N;            // wave col (channels)
 
-  const int tile = xcd_remap(blockIdx.x, a.nblk_m * a.nblk_n);
+  const int ntiles = a.nblk_m * a.nblk_n;
+  const int split = a.ksplit > 1 ? blockIdx.x / ntiles : 0;
+  const int tile = xcd_remap(a.ksplit > 1 ? blockIdx.x - split * ntiles : blockIdx.x, ntiles);
   const int m0 = (tile / a.nblk_n) * BM;    // n fastest: consecutive tiles share the pixel rows
   const int n0 = (tile % a.nblk_n) * BN;
 
@@ -156,8 +173,13 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = a.Kpad / BK;
-  LOAD_TILES(0);
+  // k-step range of this block (the whole K unless split-K; split-K is only used for 1x1 / linear
+  // layers, where the running tap state is just the channel offset)
+  const int nk_all = a.Kpad / BK;
+  const int kt0 = a.ksplit > 1 ? (int)((long long)split * nk_all / a.ksplit) : 0;
+  const int kt1 = a.ksplit > 1 ? (int)((long long)(split + 1) * nk_all / a.ksplit) : nk_all;
+  c0 = kt0 * BK;
+  LOAD_TILES(kt0);
   STORE_TILES(0);
   __syncthreads();
 
@@ -188,14 +210,14 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   } while (0)
 
   // steady state: loads of step kt+1 are in flight under the 32 MFMAs of step kt
-  for (int kt = 0; kt + 1 < nk; ++kt) {
-    const int buf = kt & 1;
+  for (int kt = kt0; kt + 1 < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
     LOAD_TILES(kt + 1);
     COMPUTE_STEP(buf);
     STORE_TILES(buf ^ 1);
     __syncthreads();
   }
-  COMPUTE_STEP((nk - 1) & 1);
+  COMPUTE_STEP((kt1 - 1 - kt0) & 1);
 #undef COMPUTE_STEP
 
   // ---- epilogue -------------------------------------------------------------------------------------
@@ -210,8 +232,12 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   const int c4 = lane & 15;                         // this lane's 4-channel group in the read-back
   const int n_lane = n0 + wn * 64 + c4 * 4;
   const bool n_ok = n_lane < a.N;
-  const float4 bv = *reinterpret_cast<const float4*>(a.bias + n_lane);
-  const bool has_res = a.res != nullptr;
+  const bool part = a.ksplit > 1;                   // split-K: raw partial sums, reduced by splitk_reduce_kernel
+  const float4 bv = part ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(a.bias + n_lane);
+  const bool has_res = !part && a.res != nullptr;
+  const int act = part ? HANDS_ACT_NONE : a.relu;
+  float* const obase = part ? a.partial + (size_t)split * a.M * a.part_ps : a.out;
+  const int ops = part ? a.part_ps : a.out_ps;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -238,15 +264,8 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
       v.y = t.y + bv.y + rv[r].y;
       v.z = t.z + bv.z + rv[r].z;
       v.w = t.w + bv.w + rv[r].w;
-      if (a.relu == HANDS_ACT_RELU) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      } else if (a.relu == HANDS_ACT_GELU) {
-        v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
-      } else if (a.relu == HANDS_ACT_LEAKY_RELU) {
-        v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;
-        v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;
-      }
-      if (m < a.M && n_ok) *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ps + n_lane) = v;
+      v = apply_act(v, act);
+      if (m < a.M && n_ok) *reinterpret_cast<float4*>(obase + (size_t)m * ops + n_lane) = v;
     }
   }
 #undef LOAD_TILES
@@ -258,14 +277,51 @@ int launch(ConvArgs& a, hipStream_t stream) {
   constexpr int BM = 64 * WAVES_M, BN = 64 * WAVES_N;
   a.nblk_m = (a.M + BM - 1) / BM;
   a.nblk_n = (a.N + BN - 1) / BN;
-  const long long nwg = (long long)a.nblk_m * a.nblk_n;
+  const long long nwg = (long long)a.nblk_m * a.nblk_n * (a.ksplit > 1 ? a.ksplit : 1);
   if (nwg <= 0 || nwg > 0x7fffffffLL) return HANDS_EINVAL;
   hipLaunchKernelGGL((conv_igemm_f32_kernel<WAVES_M, WAVES_N, STEM>), dim3((unsigned)nwg), dim3(256), 0,
                      stream, a);
   return (int)hipGetLastError();
 }
 
+// out[m][n] = act(bias[n] + sum_s partial[s][m][n] (+ res[m][n])), s in ascending order (deterministic)
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int N4, int part_ps,
+                                     const float* __restrict__ bias, const float* res, int res_ps, float* out, int out_ps,
+                                     int act) {
+  const long long total = (long long)M * N4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % N4) * 4;
+    const long long m = i / N4;
+    float4 v = *reinterpret_cast<const float4*>(partial + m * part_ps + n);
+    for (int s = 1; s < S; ++s) {
+      const float4 p = *reinterpret_cast<const float4*>(partial + ((long long)s * M + m) * part_ps + n);
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    const float4 b = *reinterpret_cast<const float4*>(bias + n);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    if (res) {
+      const float4 r = *reinterpret_cast<const float4*>(res + m * res_ps + n);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    *reinterpret_cast<float4*>(out + m * out_ps + n) = apply_act(v, act);
+  }
+}
+
+// split-K policy: depends on the layer (N, K) and on M only through a fixed threshold, so that the
+// summation order -- hence every output bit -- is the same for every batch size below the threshold
+int splitk_factor(const hands_conv_desc* d) {
+  // linear layers only (one row per sample): a convolution's M = B*Ho*Wo would cross the threshold
+  // between batch sizes and change the summation order with it
+  if (d->KH != 1 || d->KW != 1 || d->H != 1 || d->W != 1 || d->stride != 1 || d->pad != 0 || d->Cin == 4) return 1;
+  const long long M = d->B;
+  if (M > 2048 || d->Kpad < 512) return 1;
+  int s = d->Kpad / 256;
+  return s > 8 ? 8 : s;
+}
+
 }  // namespace
+
+extern "C" int hands_conv2d_splitk_factor(const hands_conv_desc* d) { return d ? splitk_factor(d) : 0; }
 
 extern "C" int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
                                      const float* bias, const float* residual, float* out,
@@ -286,7 +342,37 @@ extern "C" int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, 
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
   a.relu = d->act;
+  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0;
   hipStream_t s = (hipStream_t)stream;
   if (stem) return (d->Cout <= 64) ? launch<4, 1, true>(a, s) : launch<2, 2, true>(a, s);
   return (d->Cout <= 64) ? launch<4, 1, false>(a, s) : launch<2, 2, false>(a, s);
+}
+
+extern "C" int hands_conv2d_nhwc_splitk_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
+                                            const float* bias, const float* residual, float* out, float* workspace,
+                                            long long workspace_floats, hands_stream_t stream) {
+  if (!d) return HANDS_EINVAL;
+  const int S = splitk_factor(d);
+  const long long M = (long long)d->B * d->Ho * d->Wo;
+  const int part_ps = d->Cout;                          // Cout % 4 == 0
+  if (S <= 1 || !workspace || workspace_floats < (long long)S * M * part_ps)
+    return hands_conv2d_nhwc_f32(d, in, w_packed, bias, residual, out, stream);
+  if (!in || !w_packed || !bias || !out || d->Cin % 16 || d->Cout % 4 || d->Kpad % BK || d->in_pix_stride < d->Cin ||
+      d->out_pix_stride < d->Cout)
+    return HANDS_EINVAL;
+  ConvArgs a;
+  a.in = in; a.w = w_packed; a.bias = bias; a.res = nullptr; a.out = out;
+  a.M = (int)M; a.N = d->Cout; a.Kpad = d->Kpad;
+  a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
+  a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0;
+  a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
+  a.relu = HANDS_ACT_NONE;
+  a.ksplit = S; a.partial = workspace; a.part_ps = part_ps;
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = (d->Cout <= 64) ? launch<4, 1, false>(a, s) : launch<2, 2, false>(a, s);
+  if (rc) return rc;
+  const long long total = M * (d->Cout / 4);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(hands_grid_1d(total, 256)), dim3(256), 0, s, workspace, S, (int)M,
+                     d->Cout / 4, part_ps, bias, residual, d->res_pix_stride, out, d->out_pix_stride, d->act);
+  return (int)hipGetLastError();
 }

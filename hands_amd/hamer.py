@@ -285,6 +285,7 @@ class HAMER(nn.Module):
         stream = torch.cuda.current_stream(dev).cuda_stream
         buf = lambda n, numel: self._buf(n, numel, dev)
         gemm = lambda pc, x, rows, out, act=ACT_NONE, **kw: HandsLight._conv(L, pc, x, rows, 1, 1, out, act, stream, **kw)
+        hgemm = lambda *a, **kw: gemm(*a, splitk=True, **kw)     # per-sample rows: latency-bound head GEMMs
         lnorm = lambda x, gb, out, rows, Cc, eps, addvec=None, rpv=1: check(
             L.hands_layernorm_f32(ptr(x), ptr(gb[0]), ptr(gb[1]), ptr(out), ptr(addvec), rpv, rows, Cc, eps, stream),
             "layernorm")
@@ -301,8 +302,8 @@ class HAMER(nn.Module):
         kld = P["kpe0"].Cin
         enc, k1, kpe = buf("kpe_enc", B2 * kld), buf("kpe_h", B2 * Cd), buf("kpe", B2 * Cd)
         check(L.hands_kpe_encode_f32(ptr(center), ptr(corner), ptr(enc), B2, kld, self.n_freq, stream), "kpe_encode")
-        gemm(P["kpe0"], enc, B2, k1, ACT_RELU)
-        gemm(P["kpe2"], k1, B2, kpe, ACT_RELU)
+        hgemm(P["kpe0"], enc, B2, k1, ACT_RELU)
+        hgemm(P["kpe2"], k1, B2, kpe, ACT_RELU)
         # -- ViT-H/16 (vit.py:320-342) ---------------------------------------------------------------
         x = buf("vit_x", M * Cd)
         ho, wo = HandsLight._conv(L, P["patch"], x4, B2, S, Wc, x, ACT_NONE, stream)
@@ -328,19 +329,19 @@ class HAMER(nn.Module):
         dscale = float(DEC_HDIM ** -0.5)
         for lay in P["dec"]:
             lnorm(xd, lay["n0"], yd, B2, DEC_DIM, 1e-5)
-            gemm(lay["v"], yd, B2, v512)
-            gemm(lay["o0"], v512, B2, xd, res=xd)
+            hgemm(lay["v"], yd, B2, v512)
+            hgemm(lay["o0"], v512, B2, xd, res=xd)
             lnorm(xd, lay["n1"], yd, B2, DEC_DIM, 1e-5)
-            gemm(lay["q"], yd, B2, q512)
+            hgemm(lay["q"], yd, B2, q512)
             gemm(lay["kv"], feat, M, kv)
             check(L.hands_cross_attention_1q_f32(ptr(q512), ptr(kv), ptr(o512), B2, T, DEC_HEADS, DEC_HDIM, dscale,
                                                  stream), "cross_attention")
-            gemm(lay["o1"], o512, B2, xd, res=xd)
+            hgemm(lay["o1"], o512, B2, xd, res=xd)
             lnorm(xd, lay["n2"], yd, B2, DEC_DIM, 1e-5)
-            gemm(lay["f0"], yd, B2, hd, ACT_GELU)
-            gemm(lay["f3"], hd, B2, xd, res=xd)
+            hgemm(lay["f0"], yd, B2, hd, ACT_GELU)
+            hgemm(lay["f3"], hd, B2, xd, res=xd)
         pred = torch.empty(B2, 112, device=dev)
-        gemm(P["decout"], xd, B2, pred, res=P["init"], res_ps=0)          # dec*(token) + mean params
+        hgemm(P["decout"], xd, B2, pred, res=P["init"], res_ps=0)          # dec*(token) + mean params
         rot = torch.empty(B2, 16, 3, 3, device=dev)
         check(L.hands_rot6d_to_matrix_cols_f32(ptr(pred), 112, ptr(rot), B2, stream), "rot6d_cols")
         shape = pred[:, 96:106].contiguous()
@@ -355,10 +356,10 @@ class HAMER(nn.Module):
               "grasp_input")
         g1, g2, g3 = buf("g1", B2 * 1024), buf("g2", B2 * 512), buf("g3", B2 * 128)
         g4 = torch.empty(B2, 12, device=dev)
-        gemm(P["g0"], gin, B2, g1, ACT_RELU)
-        gemm(P["g2"], g1, B2, g2, ACT_RELU)
-        gemm(P["g4"], g2, B2, g3, ACT_RELU)
-        gemm(P["g6"], g3, B2, g4)
+        hgemm(P["g0"], gin, B2, g1, ACT_RELU)
+        hgemm(P["g2"], g1, B2, g2, ACT_RELU)
+        hgemm(P["g4"], g2, B2, g3, ACT_RELU)
+        hgemm(P["g6"], g3, B2, g4)
         grasp = xdict()
         grasp["grasp.r"] = g4[:bz, :9].contiguous()
         grasp["grasp.l"] = g4[bz:, :9].contiguous()

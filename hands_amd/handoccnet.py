@@ -195,6 +195,8 @@ class HandOccNet(nn.Module):
             HandsLight._conv(L, pc, x, B, H, W, out, act, stream, res=res, **kw)
             return out, Ho, Wo
 
+        hconv = lambda *a, **kw: conv(*a, splitk=True, **kw)     # per-sample rows: latency-bound head GEMMs
+
         # -- model.py:66-70: resize to 256x256, cat(r, l) -> NHWC4 ---------------------------------
         S = 256
         x4 = new(B2, S, S, 4)
@@ -339,9 +341,9 @@ class HandOccNet(nn.Module):
             H, W = H // 2, W // 2
         if dbg is not None:
             dbg["enc"] = x
-        f = conv(P["base0"], x, B2, 1, 1, ACT_LEAKY_RELU)[0]         # x: (B2,2,2,256) read as (B2,1024)
-        f = conv(P["base2"], f, B2, 1, 1, ACT_LEAKY_RELU)[0]
-        pred = conv(P["regs"], f, B2, 1, 1)[0].view(B2, 112)
+        f = hconv(P["base0"], x, B2, 1, 1, ACT_LEAKY_RELU)[0]         # x: (B2,2,2,256) read as (B2,1024)
+        f = hconv(P["base2"], f, B2, 1, 1, ACT_LEAKY_RELU)[0]
+        pred = hconv(P["regs"], f, B2, 1, 1)[0].view(B2, 112)
         rot = new(B2, 16, 3, 3)
         check(L.hands_rot6d_to_matrix_cols_f32(ptr(pred), 112, ptr(rot), B2, stream), "rot6d_cols")
         if dbg is not None:
@@ -360,8 +362,8 @@ class HandOccNet(nn.Module):
         gld = P["g0"].Cin
         gin = new(B2, gld)
         check(L.hands_grasp_input_f32(ptr(shape), 10, ptr(rot), ptr(shape), ptr(gin), B2, bz, 0, gld, stream), "grasp_in")
-        g = conv(P["g0"], gin, B2, 1, 1, ACT_RELU)[0]
-        g = conv(P["g2"], g, B2, 1, 1, ACT_RELU)[0]
+        g = hconv(P["g0"], gin, B2, 1, 1, ACT_RELU)[0]
+        g = hconv(P["g2"], g, B2, 1, 1, ACT_RELU)[0]
         g = conv(P["g4"], g, B2, 1, 1, ACT_RELU)[0]
         g4 = conv(P["g6"], g, B2, 1, 1)[0].view(B2, 12)
         grasp = xdict()

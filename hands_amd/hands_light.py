@@ -324,12 +324,14 @@ class HandsLight(nn.Module):
 
     # ---- kernel launch helpers ----------------------------------------------------------------
     conv_hook = None   # bench.py installs a callback here to bracket every GEMM launch with events
+    use_splitk = True       # deterministic split-K for the latency-bound head GEMMs
+    _splitk_ws = {}         # (device, stream) -> workspace tensor
     overlap_trunks = True   # run the global trunk on a second HIP stream beside the hand trunk
     trunk_chunks = (1, 2)   # (global, hand) trunk jobs, one HIP stream each
 
     @staticmethod
     def _conv(L, pc: PackedConv, x, B, H, W, out, relu, stream, res=None, in_ps=None, out_ps=None,
-              res_ps=None, x_off=0, out_off=0, res_off=0):
+              res_ps=None, x_off=0, out_off=0, res_off=0, splitk=False):
         Ho = (H + 2 * pc.pad - pc.KH) // pc.stride + 1
         Wo = (W + 2 * pc.pad - pc.KW) // pc.stride + 1
         d = ConvDesc(B, H, W, pc.Cin, Ho, Wo, pc.Cout, pc.KH, pc.KW, pc.stride, pc.pad,
@@ -339,9 +341,22 @@ class HandsLight(nn.Module):
         hook = HandsLight.conv_hook
         if hook is not None:
             hook("begin", pc, B * Ho * Wo, stream, res is not None)
-        check(L.hands_conv2d_nhwc_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
-                                      ptr(res, res_off) if res is not None else None, ptr(out, out_off),
-                                      stream), "hands_conv2d_nhwc_f32")
+        # split-K only where the caller says the rows are per-SAMPLE (head MLPs): token / pixel GEMMs
+        # would cross the library's row threshold between batch sizes and lose bit-reproducibility
+        S = L.hands_conv2d_splitk_factor(C.byref(d)) if (splitk and HandsLight.use_splitk) else 1
+        if S > 1:     # latency-bound head GEMM: deterministic split-K with a per-stream workspace
+            need = S * B * Ho * Wo * pc.Cout
+            key = (x.device, stream)
+            ws = HandsLight._splitk_ws.get(key)
+            if ws is None or ws.numel() < need:
+                ws = HandsLight._splitk_ws[key] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=x.device)
+            check(L.hands_conv2d_nhwc_splitk_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
+                                                 ptr(res, res_off) if res is not None else None, ptr(out, out_off),
+                                                 ptr(ws), ws.numel(), stream), "hands_conv2d_nhwc_splitk_f32")
+        else:
+            check(L.hands_conv2d_nhwc_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
+                                          ptr(res, res_off) if res is not None else None, ptr(out, out_off),
+                                          stream), "hands_conv2d_nhwc_f32")
         if hook is not None:
             hook("end", pc, B * Ho * Wo, stream, res is not None)
         return Ho, Wo
@@ -462,7 +477,7 @@ class HandsLight(nn.Module):
         assert h3 * w3 * 256 == P["fc7"].Cin
         ld = F + HMR_VEC
         state = buf("state", B2 * ld)
-        self._conv(L, P["fc7"], f3, B2, 1, 1, state, True, stream, out_ps=ld)
+        self._conv(L, P["fc7"], f3, B2, 1, 1, state, True, stream, out_ps=ld, splitk=True)
 
         # -- HandHMR x2 (hand_hmr.py:73-92, hmr_layer.py:67-86) ----------------------------------
         caminit4 = buf("caminit4", B2 * 4)
@@ -478,16 +493,16 @@ class HandsLight(nn.Module):
             h512a, h512b = buf(f"h512a{side}", bz * 512), buf(f"h512b{side}", bz * 512)
             x1, x2 = buf(f"x1024a{side}", bz * 1024), buf(f"x1024b{side}", bz * 1024)
             so = side * bz * ld
-            self._conv(L, hp["ci0"], state, bz, 1, 1, h512a, True, sh, in_ps=ld, x_off=so)
-            self._conv(L, hp["ci2"], h512a, bz, 1, 1, h512b, True, sh)
+            self._conv(L, hp["ci0"], state, bz, 1, 1, h512a, True, sh, in_ps=ld, x_off=so, splitk=True)
+            self._conv(L, hp["ci2"], h512a, bz, 1, 1, h512b, True, sh, splitk=True)
             self._conv(L, hp["ci4"], h512b, bz, 1, 1, caminit4, False, sh, out_off=side * bz * 4)
             check(L.hands_hmr_init_f32(ptr(state, so), ptr(caminit4, side * bz * 4), bz, ld, F, sh),
                   "hmr_init")
             for _ in range(3):
-                self._conv(L, hp["r0"], state, bz, 1, 1, x1, True, sh, in_ps=ld, x_off=so)
-                self._conv(L, hp["r3"], x1, bz, 1, 1, x2, True, sh)
+                self._conv(L, hp["r0"], state, bz, 1, 1, x1, True, sh, in_ps=ld, x_off=so, splitk=True)
+                self._conv(L, hp["r3"], x1, bz, 1, 1, x2, True, sh, splitk=True)
                 self._conv(L, hp["dec"], x2, bz, 1, 1, state, False, sh, res=state, out_ps=ld,
-                           res_ps=ld, out_off=so + F, res_off=so + F)
+                           res_ps=ld, out_off=so + F, res_off=so + F, splitk=True)
             if hs is not main:
                 ev = torch.cuda.Event()
                 ev.record(hs)
@@ -522,9 +537,9 @@ class HandsLight(nn.Module):
                                       F, gld, stream), "grasp_input")
         g1, g2, g3 = buf("g1", B2 * 1024), buf("g2", B2 * 512), buf("g3", B2 * 128)
         g4 = torch.empty(B2, 12, device=dev)
-        self._conv(L, P["g0"], gin, B2, 1, 1, g1, True, stream)
-        self._conv(L, P["g2"], g1, B2, 1, 1, g2, True, stream)
-        self._conv(L, P["g4"], g2, B2, 1, 1, g3, True, stream)
+        self._conv(L, P["g0"], gin, B2, 1, 1, g1, True, stream, splitk=True)
+        self._conv(L, P["g2"], g1, B2, 1, 1, g2, True, stream, splitk=True)
+        self._conv(L, P["g4"], g2, B2, 1, 1, g3, True, stream, splitk=True)
         self._conv(L, P["g6"], g3, B2, 1, 1, g4, False, stream)
         grasp = xdict()
         grasp["grasp.r"] = g4[:bz, :9].contiguous()

@@ -67,6 +67,19 @@ int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, const float
                           const float* bias, const float* residual, float* out,
                           hands_stream_t stream);
 
+/* Deterministic split-K form of the same layer for latency-bound GEMMs (1x1 / linear layers with few
+ * rows and a long K: the HMR / decoder / regressor heads).  hands_conv2d_splitk_factor() returns the
+ * number of K slices S the library would use (1 = no split): S = min(8, Kpad/256) for linear layers
+ * (H = W = 1) with B <= 2048 rows and Kpad >= 512 -- a function of the layer only, so every output bit
+ * is independent of the batch size up to 2048 rows.  The caller provides
+ * `workspace` of >= S * M * Cout floats (M = B*Ho*Wo); slices write raw partial sums, a second launch
+ * adds them in ascending slice order and applies bias / residual / activation.  With S == 1 or a
+ * too-small workspace the call is identical to hands_conv2d_nhwc_f32. */
+int hands_conv2d_splitk_factor(const hands_conv_desc* d);
+int hands_conv2d_nhwc_splitk_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
+                                 const float* bias, const float* residual, float* out, float* workspace,
+                                 long long workspace_floats, hands_stream_t stream);
+
 /* NCHW (B,3,H,W) image batch -> NHWC with C padded to 4 (4th channel = 0).
  * Replaces the implicit layout of inputs["img"|"r_img"|"l_img"] (model.py:188,238-239). */
 int hands_nchw3_to_nhwc4_f32(const float* in, float* out, int B, int H, int W, hands_stream_t stream);
