@@ -1,0 +1,105 @@
+// Ablation harness for the conv_igemm main loop (dev tool, not part of the library).
+// Plain GEMM D[n][m] = sum_k W[n][k] X[m][k] with the same tiling; VARIANT selects what is removed.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ float f4e(const float4& v, int t) { return t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w)); }
+
+// VARIANT 0: full; 1: no global loads/ds_write in loop (LDS content reused); 2: no LDS reads (register operands);
+// 3: full but only 2 blocks/CU (extra LDS); 4: MFMA only (no loads, no LDS, no barrier)
+template <int VARIANT>
+__global__ void __launch_bounds__(256, 2) gemm_kernel(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ D,
+                                                      int M, int N, int K) {
+  constexpr int BM = 128, BN = 128, BK = 16, LR = 20;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LR + (VARIANT == 3 ? 12000 : 0)];
+  float* sX = lds; float* sW = lds + 2 * BM * LR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int nbn = N / BN;
+  const int m0 = (blockIdx.x / nbn) * BM, n0 = (blockIdx.x % nbn) * BN;
+  const int srow = tid >> 2, chunk = tid & 3;
+  const float* xp0 = X + (size_t)(m0 + srow) * K + chunk * 4; const float* xp1 = xp0 + (size_t)64 * K;
+  const float* wp0 = W + (size_t)(n0 + srow) * K + chunk * 4; const float* wp1 = wp0 + (size_t)64 * K;
+  float4 xr0, xr1, wr0, wr1;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = K / BK;
+#define LOADT(kt) { xr0 = *(const float4*)(xp0 + (kt) * BK); xr1 = *(const float4*)(xp1 + (kt) * BK); wr0 = *(const float4*)(wp0 + (kt) * BK); wr1 = *(const float4*)(wp1 + (kt) * BK); }
+#define STORET(buf) { float* dx = sX + (buf) * BM * LR + srow * LR + chunk * 4; float* dw = sW + (buf) * BN * LR + srow * LR + chunk * 4; \
+    *(float4*)dx = xr0; *(float4*)(dx + 64 * LR) = xr1; *(float4*)dw = wr0; *(float4*)(dw + 64 * LR) = wr1; }
+  LOADT(0); STORET(0); __syncthreads();
+  const int frag = (lane & 31) * LR + (lane >> 5) * 4;
+  const float* fw = sW + wn * 64 * LR + frag; const float* fx = sX + wm * 64 * LR + frag;
+  float4 wf[2][2], xf[2][2];
+  if (VARIANT == 2 || VARIANT == 4) for (int kk = 0; kk < 2; ++kk) for (int i = 0; i < 2; ++i) { wf[i][kk] = *(const float4*)(fw + i * 32 * LR + kk * 8); xf[i][kk] = *(const float4*)(fx + i * 32 * LR + kk * 8); }
+  if (VARIANT == 5) {
+    LOADT(1);
+    for (int kt = 0; kt < nk - 1; ++kt) {
+      const int buf = kt & 1;
+      STORET(buf ^ 1);                        // tile kt+1 (loaded one iteration ago) -> other buffer
+      { const int k2 = kt + 2 < nk ? kt + 2 : nk - 1; LOADT(k2); }
+      for (int kk = 0; kk < 2; ++kk) for (int i = 0; i < 2; ++i) {
+        wf[i][kk] = *(const float4*)(fw + buf * BN * LR + i * 32 * LR + kk * 8);
+        xf[i][kk] = *(const float4*)(fx + buf * BM * LR + i * 32 * LR + kk * 8); }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(wf[i][kk], t), f4e(xf[j][kk], t), acc[i][j], 0, 0, 0);
+      __syncthreads();
+    }
+  } else
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    const int buf = (VARIANT == 1) ? 0 : (kt & 1);
+    if (VARIANT == 0 || VARIANT == 2 || VARIANT == 3) LOADT(kt + 1);
+    if (VARIANT != 2 && VARIANT != 4)
+      for (int kk = 0; kk < 2; ++kk) for (int i = 0; i < 2; ++i) {
+        wf[i][kk] = *(const float4*)(fw + buf * BN * LR + i * 32 * LR + kk * 8);
+        xf[i][kk] = *(const float4*)(fx + buf * BM * LR + i * 32 * LR + kk * 8); }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(wf[i][kk], t), f4e(xf[j][kk], t), acc[i][j], 0, 0, 0);
+    if (VARIANT == 0 || VARIANT == 2 || VARIANT == 3) STORET(buf ^ 1);
+    if (VARIANT != 4) __syncthreads();
+  }
+  const int half = lane >> 5;
+  for (int j = 0; j < 2; ++j) for (int i = 0; i < 2; ++i) for (int q = 0; q < 4; ++q) {
+    const int m = m0 + wm * 64 + j * 32 + (lane & 31), n = n0 + wn * 64 + i * 32 + q * 8 + half * 4;
+    *(float4*)(D + (size_t)m * N + n) = make_float4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+  }
+}
+template <int V> void run(const float* X, const float* W, float* D, int M, int N, int K, const char* name) {
+  dim3 g((M / 128) * (N / 128));
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(gemm_kernel<V>, g, dim3(256), 0, 0, X, W, D, M, N, K);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  hipEventRecord(a); const int R = 20;
+  for (int i = 0; i < R; ++i) hipLaunchKernelGGL(gemm_kernel<V>, g, dim3(256), 0, 0, X, W, D, M, N, K);
+  hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); ms /= R;
+  printf("%-34s %8.1f us  %6.1f TF/s\n", name, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
+}
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 24576, N = argc > 2 ? atoi(argv[2]) : 3840, K = argc > 3 ? atoi(argv[3]) : 1280;
+  float *X, *W, *D; hipMalloc(&X, (size_t)M * K * 4); hipMalloc(&W, (size_t)N * K * 4); hipMalloc(&D, (size_t)M * N * 4);
+  std::vector<float> h((size_t)M * K); for (auto& v : h) v = (rand() / (float)RAND_MAX) * 2 - 1; hipMemcpy(X, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  h.resize((size_t)N * K); for (auto& v : h) v = (rand() / (float)RAND_MAX) * 2 - 1; hipMemcpy(W, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  printf("M=%d N=%d K=%d\n", M, N, K);
+  for (int round = 0; round < 3; ++round) {
+    printf("-- round %d\n", round);
+    run<0>(X, W, D, M, N, K, "0 full");
+    run<5>(X, W, D, M, N, K, "5 store-at-top, load 2 ahead");
+    run<1>(X, W, D, M, N, K, "1 no global loads / ds_write");
+    run<2>(X, W, D, M, N, K, "2 no ds_read (reg operands)");
+    run<3>(X, W, D, M, N, K, "3 full, 2 blocks/CU");
+    run<4>(X, W, D, M, N, K, "4 MFMA only");
+  }
+  return 0;
+}
