@@ -82,6 +82,8 @@ SIGNATURES = {
     "hands_mano_pose_aa_f32": [C.POINTER(ManoConsts), _P, _P, _I, _P, _I, _P, _P, _I, _P],
     "hands_gt_targets_f32": [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _P],
     "hands_unnormalize_kp2d_f32": [_P, _P, C.c_longlong, _F, _P],
+    "hands_frontend_boxes_f32": [_P, _P, _I, _P, _I, _I, _I, C.c_double] + [_P] * 10 + [_P],
+    "hands_warp_affine_cubic_norm_f32": [_P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P],
 }
 EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string")
 

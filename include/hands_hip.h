@@ -301,6 +301,29 @@ int hands_gt_targets_f32(const float* joints, const float* verts, const float* j
 int hands_unnormalize_kp2d_f32(const float* x, float* out, long long n, float img_res,
                                hands_stream_t stream);
 
+/* ---- (f2) crop / KPE front-end, the step before the path -------------------------------------------
+ * hands_frontend_boxes_f32: per sample and hand, from the normalised GT 2-D joints (B,21,ld>=2):
+ *   box [x0,y0,w,h] = int16-truncated min/max of ((j+1)/2)*(res-1), clipped to [0,res-1]
+ *                                                  (src/datasets/hands_light_dataset.py:137-152);
+ *   crop window [x0,y0,x1,y1] of crop_and_pad (common/data_utils.py:495-509; an empty box -> whole image);
+ *   the float32 2x3 affine gen_trans_from_patch_cv builds for it (common/data_utils.py:56-91, rot=0);
+ *   center (2) / corner (8) angles atan2(p - c, f) of the window (hands_light_dataset.py:256-279).
+ *   bbox_og = the box itself, or [0,0,res-1,res-1] when empty (hands_light_dataset.py:145-152).
+ * hands_warp_affine_cubic_norm_f32: cv2.warpAffine(src, trans, (Wo,Ho), INTER_CUBIC) with constant-0
+ *   border (generate_patch_image_clean, common/data_utils.py:423-460), then clip to [0,1] and
+ *   (x - mean)/std (hands_light_dataset.py:171-178,528).  src (B,3,H,W) in [0,1], out (B,3,Ho,Wo);
+ *   trans (B,6) device pointer or NULL for the identity; mean3/std3 are HOST pointers to 3 floats.
+ *   OpenCV is not vendored by the reference: the kernel follows its published fixed-point cubic
+ *   remap (see oracle/frontend_oracle.py, "parity unpinned"). */
+int hands_frontend_boxes_f32(const float* j2d_r, const float* j2d_l, int ld, const float* K, int B,
+                             int img_res, int out_res, double bbox_scale,
+                             int32_t* bbox_r, int32_t* bbox_l, int32_t* bbox_og_r, int32_t* bbox_og_l,
+                             float* trans_r, float* trans_l, float* center_r, float* center_l,
+                             float* corner_r, float* corner_l, hands_stream_t stream);
+int hands_warp_affine_cubic_norm_f32(const float* src, const float* trans, float* out, int B, int H, int W,
+                                     int Ho, int Wo, const float* mean3, const float* std3,
+                                     hands_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
