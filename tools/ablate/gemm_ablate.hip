@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float f4e(const float4& v, int t) { return t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w)); }
@@ -33,6 +34,82 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const float* __restrict__ 
   const float* fw = sW + wn * 64 * LR + frag; const float* fx = sX + wm * 64 * LR + frag;
   float4 wf[2][2], xf[2][2];
   if (VARIANT == 2 || VARIANT == 4) for (int kk = 0; kk < 2; ++kk) for (int i = 0; i < 2; ++i) { wf[i][kk] = *(const float4*)(fw + i * 32 * LR + kk * 8); xf[i][kk] = *(const float4*)(fx + i * 32 * LR + kk * 8); }
+  if (VARIANT == 6) {
+    // direct global->LDS (global_load_lds_dwordx4): unpadded 64-B rows, 16-B chunk XOR-swizzled by (row>>2)&3
+    // on the SOURCE side (lane picks which k-chunk it fetches) and on the fragment reads.
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void gbl_void;
+    float* sX6 = lds; float* sW6 = lds + 2 * BM * 16;
+    const int kc = (tid & 3) ^ ((tid >> 4) & 3);
+    const float* gx0 = X + (size_t)(m0 + srow) * K + kc * 4; const float* gx1 = gx0 + (size_t)64 * K;
+    const float* gw0 = W + (size_t)(n0 + srow) * K + kc * 4; const float* gw1 = gw0 + (size_t)64 * K;
+#define GLDS(kt, buf) { \
+    __builtin_amdgcn_global_load_lds((gbl_void*)(gx0 + (kt) * BK), (lds_void*)(sX6 + (buf) * BM * 16 + (wave * 16) * 16), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((gbl_void*)(gx1 + (kt) * BK), (lds_void*)(sX6 + (buf) * BM * 16 + (64 + wave * 16) * 16), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((gbl_void*)(gw0 + (kt) * BK), (lds_void*)(sW6 + (buf) * BN * 16 + (wave * 16) * 16), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((gbl_void*)(gw1 + (kt) * BK), (lds_void*)(sW6 + (buf) * BN * 16 + (64 + wave * 16) * 16), 16, 0, 0); }
+    __syncthreads();   // the register-staged prologue above wrote the padded layout; start clean
+    GLDS(0, 0);
+    __syncthreads();
+    const int sw = (lane >> 2) & 3, h = lane >> 5;
+    const int o0 = (lane & 31) * 16 + ((h ^ sw) << 2), o1 = (lane & 31) * 16 + (((2 + h) ^ sw) << 2);
+    const float* fw6 = sW6 + wn * 64 * 16; const float* fx6 = sX6 + wm * 64 * 16;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) GLDS(kt + 1, buf ^ 1);
+      for (int i = 0; i < 2; ++i) {
+        wf[i][0] = *(const float4*)(fw6 + buf * BN * 16 + i * 32 * 16 + o0); wf[i][1] = *(const float4*)(fw6 + buf * BN * 16 + i * 32 * 16 + o1);
+        xf[i][0] = *(const float4*)(fx6 + buf * BM * 16 + i * 32 * 16 + o0); xf[i][1] = *(const float4*)(fx6 + buf * BM * 16 + i * 32 * 16 + o1); }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(wf[i][kk], t), f4e(xf[j][kk], t), acc[i][j], 0, 0, 0);
+      __syncthreads();
+    }
+  } else
+  if (VARIANT == 7) {
+    // direct global->LDS (global_load_lds_dwordx4): unpadded 64-B rows, 16-B chunk XOR-swizzled by (row>>2)&3
+    // on the SOURCE side (lane picks which k-chunk it fetches) and on the fragment reads.
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void gbl_void;
+    float* sX6 = lds; float* sW6 = lds + 2 * BM * 16;
+    const int kc = (tid & 3) ^ ((tid >> 4) & 3);
+    const float* gx0 = X + (size_t)(m0 + srow) * K + kc * 4; const float* gx1 = gx0 + (size_t)64 * K;
+    const float* gw0 = W + (size_t)(n0 + srow) * K + kc * 4; const float* gw1 = gw0 + (size_t)64 * K;
+    const unsigned lx = (unsigned)(size_t)(lds_void*)sX6 + __builtin_amdgcn_readfirstlane(wave) * 1024u;
+    const unsigned lw = (unsigned)(size_t)(lds_void*)sW6 + __builtin_amdgcn_readfirstlane(wave) * 1024u;
+#define GLDS1(gsrc, ldst) { unsigned keep; asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory"); }
+#define GLDS7(kt, buf) { GLDS1(gx0 + (kt) * BK, lx + (buf) * (BM * 64)); GLDS1(gx1 + (kt) * BK, lx + (buf) * (BM * 64) + 4096u); \
+    GLDS1(gw0 + (kt) * BK, lw + (buf) * (BN * 64)); GLDS1(gw1 + (kt) * BK, lw + (buf) * (BN * 64) + 4096u); }
+    __syncthreads();   // the register-staged prologue above wrote the padded layout; start clean
+    GLDS7(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int sw = (lane >> 2) & 3, h = lane >> 5;
+    const int o0 = (lane & 31) * 16 + ((h ^ sw) << 2), o1 = (lane & 31) * 16 + (((2 + h) ^ sw) << 2);
+    const float* fw6 = sW6 + wn * 64 * 16; const float* fx6 = sX6 + wm * 64 * 16;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) GLDS7(kt + 1, buf ^ 1);
+      for (int i = 0; i < 2; ++i) {
+        wf[i][0] = *(const float4*)(fw6 + buf * BN * 16 + i * 32 * 16 + o0); wf[i][1] = *(const float4*)(fw6 + buf * BN * 16 + i * 32 * 16 + o1);
+        xf[i][0] = *(const float4*)(fx6 + buf * BM * 16 + i * 32 * 16 + o0); xf[i][1] = *(const float4*)(fx6 + buf * BM * 16 + i * 32 * 16 + o1); }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(wf[i][kk], t), f4e(xf[j][kk], t), acc[i][j], 0, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else
   if (VARIANT == 5) {
     LOADT(1);
     for (int kt = 0; kt < nk - 1; ++kt) {
@@ -100,6 +177,21 @@ int main(int argc, char** argv) {
     run<2>(X, W, D, M, N, K, "2 no ds_read (reg operands)");
     run<3>(X, W, D, M, N, K, "3 full, 2 blocks/CU");
     run<4>(X, W, D, M, N, K, "4 MFMA only");
+    run<6>(X, W, D, M, N, K, "6 global_load_lds direct");
+    run<7>(X, W, D, M, N, K, "7 global_load_lds asm, own waits");
+  }
+  for (int var = 6; var <= 7; ++var) {  // spot-check variants 6, 7 against a host dot product
+    hipMemset(D, 0, (size_t)M * N * 4);
+    if (var == 6) hipLaunchKernelGGL(gemm_kernel<6>, dim3((M / 128) * (N / 128)), dim3(256), 0, 0, X, W, D, M, N, K);
+    else hipLaunchKernelGGL(gemm_kernel<7>, dim3((M / 128) * (N / 128)), dim3(256), 0, 0, X, W, D, M, N, K);
+    hipDeviceSynchronize();
+    std::vector<float> hx((size_t)M * K), hw((size_t)N * K), hd((size_t)M * N);
+    hipMemcpy(hx.data(), X, hx.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(hw.data(), W, hw.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(hd.data(), D, hd.size() * 4, hipMemcpyDeviceToHost);
+    double worst = 0; for (int s = 0; s < 4000; ++s) { const int m = rand() % M, n = rand() % N; double acc = 0;
+      for (int k = 0; k < K; ++k) acc += (double)hx[(size_t)m * K + k] * hw[(size_t)n * K + k];
+      const double e = fabs(acc - hd[(size_t)m * N + n]); if (e > worst) worst = e; }
+    printf("variant %d spot check: max abs err %.3e (K=%d)\n", var, worst, K);
   }
   return 0;
 }
