@@ -173,12 +173,18 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // k-step range of this block (the whole K unless split-K; split-K is only used for 1x1 / linear
-  // layers, where the running tap state is just the channel offset)
+  // k-step range of this block (the whole K unless split-K) and the running tap state at its start
   const int nk_all = a.Kpad / BK;
   const int kt0 = a.ksplit > 1 ? (int)((long long)split * nk_all / a.ksplit) : 0;
   const int kt1 = a.ksplit > 1 ? (int)((long long)(split + 1) * nk_all / a.ksplit) : nk_all;
-  c0 = kt0 * BK;
+  if constexpr (!STEM) {
+    if (a.ksplit > 1) {
+      const int tap0 = (kt0 * BK) / a.Cin;
+      c0 = kt0 * BK - tap0 * a.Cin;
+      kh = tap0 / a.KW;
+      kw = tap0 - kh * a.KW;
+    }
+  }
   LOAD_TILES(kt0);
   STORE_TILES(0);
   __syncthreads();
@@ -348,31 +354,44 @@ extern "C" int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, 
   return (d->Cout <= 64) ? launch<4, 1, false>(a, s) : launch<2, 2, false>(a, s);
 }
 
-extern "C" int hands_conv2d_nhwc_splitk_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
-                                            const float* bias, const float* residual, float* out, float* workspace,
-                                            long long workspace_floats, hands_stream_t stream) {
+extern "C" int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
+                                              const float* bias, const float* residual, float* out, int S,
+                                              float* workspace, long long workspace_floats, hands_stream_t stream) {
   if (!d) return HANDS_EINVAL;
-  const int S = splitk_factor(d);
   const long long M = (long long)d->B * d->Ho * d->Wo;
   const int part_ps = d->Cout;                          // Cout % 4 == 0
+  if (S > d->Kpad / BK) S = d->Kpad / BK;
   if (S <= 1 || !workspace || workspace_floats < (long long)S * M * part_ps)
     return hands_conv2d_nhwc_f32(d, in, w_packed, bias, residual, out, stream);
-  if (!in || !w_packed || !bias || !out || d->Cin % 16 || d->Cout % 4 || d->Kpad % BK || d->in_pix_stride < d->Cin ||
-      d->out_pix_stride < d->Cout)
+  if (!in || !w_packed || !bias || !out || d->B <= 0 || d->Cout % 4 || d->Kpad % BK || d->Kpad < d->KH * d->KW * d->Cin ||
+      d->in_pix_stride < d->Cin || d->out_pix_stride < d->Cout || S > 64)
     return HANDS_EINVAL;
+  const bool stem = d->Cin == 4;
+  if (!stem && d->Cin % 16) return HANDS_EINVAL;
+  if ((long long)d->B * d->H * d->W * d->in_pix_stride >= (1LL << 31) || M >= (1LL << 31)) return HANDS_EINVAL;
   ConvArgs a;
   a.in = in; a.w = w_packed; a.bias = bias; a.res = nullptr; a.out = out;
   a.M = (int)M; a.N = d->Cout; a.Kpad = d->Kpad;
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
-  a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
   a.relu = HANDS_ACT_NONE;
   a.ksplit = S; a.partial = workspace; a.part_ps = part_ps;
   hipStream_t s = (hipStream_t)stream;
-  const int rc = (d->Cout <= 64) ? launch<4, 1, false>(a, s) : launch<2, 2, false>(a, s);
+  int rc;
+  if (stem) rc = (d->Cout <= 64) ? launch<4, 1, true>(a, s) : launch<2, 2, true>(a, s);
+  else rc = (d->Cout <= 64) ? launch<4, 1, false>(a, s) : launch<2, 2, false>(a, s);
   if (rc) return rc;
   const long long total = M * (d->Cout / 4);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(hands_grid_1d(total, 256)), dim3(256), 0, s, workspace, S, (int)M,
                      d->Cout / 4, part_ps, bias, residual, d->res_pix_stride, out, d->out_pix_stride, d->act);
   return (int)hipGetLastError();
+}
+
+extern "C" int hands_conv2d_nhwc_splitk_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
+                                            const float* bias, const float* residual, float* out, float* workspace,
+                                            long long workspace_floats, hands_stream_t stream) {
+  if (!d) return HANDS_EINVAL;
+  return hands_conv2d_nhwc_splitk_n_f32(d, in, w_packed, bias, residual, out, splitk_factor(d), workspace,
+                                        workspace_floats, stream);
 }

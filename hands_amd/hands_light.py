@@ -325,6 +325,9 @@ class HandsLight(nn.Module):
     # ---- kernel launch helpers ----------------------------------------------------------------
     conv_hook = None   # bench.py installs a callback here to bracket every GEMM launch with events
     use_splitk = True       # deterministic split-K for the latency-bound head GEMMs
+    latency_mode = False    # opt-in small-batch serving mode: split-K on every layer with <= 128 output tiles
+                            # (results then depend on the batch size at the 1e-7 level; the default keeps
+                            # every output bit independent of the batch size)
     _splitk_ws = {}         # (device, stream) -> workspace tensor
     overlap_trunks = True   # run the global trunk on a second HIP stream beside the hand trunk
     trunk_chunks = (1, 2)   # (global, hand) trunk jobs, one HIP stream each
@@ -344,15 +347,21 @@ class HandsLight(nn.Module):
         # split-K only where the caller says the rows are per-SAMPLE (head MLPs): token / pixel GEMMs
         # would cross the library's row threshold between batch sizes and lose bit-reproducibility
         S = L.hands_conv2d_splitk_factor(C.byref(d)) if (splitk and HandsLight.use_splitk) else 1
-        if S > 1:     # latency-bound head GEMM: deterministic split-K with a per-stream workspace
+        if HandsLight.latency_mode:
+            # small-batch serving: a layer with a handful of output tiles walks a K of 2304-4608 serially
+            # on a few CUs; cut K so that ~256 workgroups exist, at least 8 k-steps (128 floats) per slice
+            bm, bn = (256, 64) if pc.Cout <= 64 else (128, 128)
+            tiles = -(-(B * Ho * Wo) // bm) * -(-pc.Cout // bn)
+            S = max(S, min(256 // tiles, pc.Kpad // 128, 32)) if tiles <= 128 else S
+        if S > 1:     # latency-bound GEMM: deterministic split-K with a per-stream workspace
             need = S * B * Ho * Wo * pc.Cout
             key = (x.device, stream)
             ws = HandsLight._splitk_ws.get(key)
             if ws is None or ws.numel() < need:
                 ws = HandsLight._splitk_ws[key] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=x.device)
-            check(L.hands_conv2d_nhwc_splitk_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
-                                                 ptr(res, res_off) if res is not None else None, ptr(out, out_off),
-                                                 ptr(ws), ws.numel(), stream), "hands_conv2d_nhwc_splitk_f32")
+            check(L.hands_conv2d_nhwc_splitk_n_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
+                                                   ptr(res, res_off) if res is not None else None, ptr(out, out_off),
+                                                   S, ptr(ws), ws.numel(), stream), "hands_conv2d_nhwc_splitk_n_f32")
         else:
             check(L.hands_conv2d_nhwc_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
                                           ptr(res, res_off) if res is not None else None, ptr(out, out_off),

@@ -79,6 +79,13 @@ int hands_conv2d_splitk_factor(const hands_conv_desc* d);
 int hands_conv2d_nhwc_splitk_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
                                  const float* bias, const float* residual, float* out, float* workspace,
                                  long long workspace_floats, hands_stream_t stream);
+/* Same with a caller-chosen slice count S (clamped to Kpad/16; any convolution, not only linear
+ * layers): the small-batch serving mode, where a layer has a handful of output tiles and a K of
+ * 2304-4608 walked serially.  The summation order depends on S, so results are reproducible for a
+ * given (layer, S) but not bit-identical to the S = 1 call. */
+int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
+                                   const float* bias, const float* residual, float* out, int S,
+                                   float* workspace, long long workspace_floats, hands_stream_t stream);
 
 /* NCHW (B,3,H,W) image batch -> NHWC with C padded to 4 (4th channel = 0).
  * Replaces the implicit layout of inputs["img"|"r_img"|"l_img"] (model.py:188,238-239). */

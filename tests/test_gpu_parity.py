@@ -85,6 +85,33 @@ def test_conv_igemm_vs_torch(case):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] * c[2] * c[3] <= 3000])
+def test_conv_igemm_latency_mode_split_k(case):
+    """Caller-chosen split-K on convolutions (small-batch serving mode): same result as the unsplit
+    launch up to the fp32 re-association of S partial sums."""
+    B, Cin, H, W, Cout, k, stride, pad, relu, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Cout, Ho, Wo, generator=g) if use_res else None
+    ref = F.conv2d(x.double(), w.double(), bias.double(), stride=stride, padding=pad)
+    if res is not None:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    HandsLight.latency_mode = True
+    try:
+        got = _run_conv(x, w, bias, stride, pad, relu, res)
+        again = _run_conv(x, w, bias, stride, pad, relu, res)
+    finally:
+        HandsLight.latency_mode = False
+    assert torch.equal(got, again)                                 # deterministic
+    err = (got.double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
 def test_stem_conv_bn_fold_vs_torch():
     g = torch.Generator().manual_seed(3)
     x = torch.randn(3, 3, 224, 224, generator=g)
@@ -286,6 +313,43 @@ def test_forward_vs_golden(golden_dir, gpu_model, seed):
         assert verr < 1e-6, verr      # north star: fp32 within 1e-3 mm
         mp = O.mpjpe_ra_mm(out[f"mano.joints3d.{hn}"].cpu(), torch.from_numpy(d[f"out/mano.joints3d.{hn}"]))
         assert mp < 1e-3, mp          # "MPJPE vs ref" of the north star, mm
+
+
+@pytest.mark.parametrize("seed", [0, 2])
+def test_forward_latency_mode_vs_golden(golden_dir, gpu_model, seed):
+    """Small-batch serving mode (split-K on every layer with few output tiles): same parity bar."""
+    d = np.load(os.path.join(golden_dir, f"hands_light_bz2_seed{seed}.npz"))
+    inputs, meta_info = synthetic_inputs(2, seed, device=DEV)
+    meta_info["is_flipped"] = torch.from_numpy(d["is_flipped"]).to(DEV)
+    HandsLight.latency_mode = True
+    try:
+        out = gpu_model(inputs, meta_info)
+        torch.cuda.synchronize()
+    finally:
+        HandsLight.latency_mode = False
+    for hn in "rl":
+        verr = np.abs(out[f"mano.vertices.{hn}"].cpu().numpy() - d[f"out/mano.vertices.{hn}"]).max()
+        assert verr < 1e-6, verr
+        mp = O.mpjpe_ra_mm(out[f"mano.joints3d.{hn}"].cpu(), torch.from_numpy(d[f"out/mano.joints3d.{hn}"]))
+        assert mp < 1e-3, mp
+
+
+def test_graphed_forward_is_bit_identical(gpu_model):
+    """hipGraph capture of the whole forward (5 streams, fork/join events): replay == eager, bit for bit,
+    also on new inputs copied into the captured buffers."""
+    from hands_amd import GraphedForward
+    inputs, meta_info = synthetic_inputs(2, 0, device=DEV)
+    gf = GraphedForward(gpu_model, inputs, meta_info)
+    for seed in (0, 7):
+        inputs, meta_info = synthetic_inputs(2, seed, device=DEV)
+        eager = {k: v.clone() for k, v in gpu_model(inputs, meta_info).items()}
+        got = gf(inputs, meta_info)
+        torch.cuda.synchronize()
+        for k in eager:
+            assert torch.equal(got[k], eager[k]), (seed, k)
+    bad, meta3 = synthetic_inputs(3, 0, device=DEV)
+    with pytest.raises(ValueError):
+        gf(bad, meta3)
 
 
 def test_forward_vs_oracle_with_flips(recipe_sd, gpu_model):

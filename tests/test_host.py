@@ -210,3 +210,12 @@ def test_load_reference_style_checkpoint(tmp_path, recipe_model):
     assert rep.missing_keys == [] and rep.unexpected_keys == ["mano_r.mano.unknown_smplx_buffer"]
     for k, v in recipe_model.state_dict().items():
         assert torch.equal(m.state_dict()[k], v), k
+
+
+def test_graphed_forward_and_frontend_refuse_cpu():
+    import torch
+    import hands_amd
+    with pytest.raises(RuntimeError):
+        hands_amd.GraphedForward(None, {"img": torch.zeros(1, 3, 8, 8)}, {})
+    with pytest.raises(RuntimeError):
+        hands_amd.HandsFrontEnd().boxes(torch.zeros(1, 21, 2), torch.zeros(1, 21, 2), torch.eye(3)[None])
