@@ -131,8 +131,8 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const float* __restrict__ 
     }
   } else
   for (int kt = 0; kt + 1 < nk; ++kt) {
-    const int buf = (VARIANT == 1) ? 0 : (kt & 1);
-    if (VARIANT == 0 || VARIANT == 2 || VARIANT == 3) LOADT(kt + 1);
+    const int buf = (VARIANT == 1 || VARIANT == 8) ? 0 : (kt & 1);
+    if (VARIANT == 0 || VARIANT == 2 || VARIANT == 3 || VARIANT == 8) LOADT(kt + 1);
     if (VARIANT != 2 && VARIANT != 4)
       for (int kk = 0; kk < 2; ++kk) for (int i = 0; i < 2; ++i) {
         wf[i][kk] = *(const float4*)(fw + buf * BN * LR + i * 32 * LR + kk * 8);
@@ -145,7 +145,9 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const float* __restrict__ 
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(wf[i][kk], t), f4e(xf[j][kk], t), acc[i][j], 0, 0, 0);
-    if (VARIANT == 0 || VARIANT == 2 || VARIANT == 3) STORET(buf ^ 1);
+    if (VARIANT == 0 || VARIANT == 2 || VARIANT == 3 || VARIANT == 9) STORET(buf ^ 1);
+    if (VARIANT == 8) { asm volatile("" :: "v"(xr0.x), "v"(xr0.y), "v"(xr0.z), "v"(xr0.w), "v"(xr1.x), "v"(xr1.y), "v"(xr1.z), "v"(xr1.w));
+                        asm volatile("" :: "v"(wr0.x), "v"(wr0.y), "v"(wr0.z), "v"(wr0.w), "v"(wr1.x), "v"(wr1.y), "v"(wr1.z), "v"(wr1.w)); }
     if (VARIANT != 4) __syncthreads();
   }
   const int half = lane >> 5;
@@ -177,6 +179,8 @@ int main(int argc, char** argv) {
     run<2>(X, W, D, M, N, K, "2 no ds_read (reg operands)");
     run<3>(X, W, D, M, N, K, "3 full, 2 blocks/CU");
     run<4>(X, W, D, M, N, K, "4 MFMA only");
+    run<8>(X, W, D, M, N, K, "8 global loads, no ds_write");
+    run<9>(X, W, D, M, N, K, "9 ds_write, no global loads");
     run<6>(X, W, D, M, N, K, "6 global_load_lds direct");
     run<7>(X, W, D, M, N, K, "7 global_load_lds asm, own waits");
   }
