@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="one HIP stream for everything (every launch alone on the chip): the mode the "
                          "per-kernel rocprofv3 averages in profiles/ are taken in")
+    ap.add_argument("--latency-mode", action="store_true",
+                    help="HandsLight.latency_mode: split-K on every launch with <= 128 output tiles (small-batch serving)")
     ap.add_argument("--cpu-bz", type=int, default=16)
     ap.add_argument("--layer-report", default="", help="write a per-launch CSV of the GEMM kernel here")
     args = ap.parse_args()
@@ -103,6 +105,8 @@ def main():
     flop_per_hand = {"hamer_light": 251e9, "handoccnet_light": 36.2e9}.get(args.workload, 12.77e9)
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model = model.to(dev).eval()
+    if args.latency_mode:
+        HandsLight.latency_mode = True
     if args.serial:
         HandsLight.overlap_trunks = False
     if os.environ.get("HANDS_CHUNKS"):
@@ -256,7 +260,8 @@ def main():
                                 "hands_light ResNet-50 x3 + feature_conv + HMR + MANO, 224x224, "
                                 f"bz={bz} samples/GPU ({2 * bz} hands, {3 * bz} trunk passes)"),
                    "per_gpu_batch": bz, "global_batch": bz * n_gpus, "img_res": 224,
-                   "parallelism": f"dp{n_gpus}" + ("+allgather" if n_gpus > 1 else "")},
+                   "parallelism": f"dp{n_gpus}" + ("+allgather" if n_gpus > 1 else ""),
+                   "latency_mode": bool(args.latency_mode)},
         "hands_per_sec_per_gpu": round(hands_per_s / n_gpus, 1),
         "path_tflops": round(hands_per_s * flop_per_hand / 1e12 / n_gpus, 2),
         "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,

@@ -35,6 +35,18 @@ HANDOCC_DEFAULT_ARGS = _Args(pos_enc="center+corner_latent", n_freq_pos_enc=4, u
 NTOK, CF, HEADS = 1024, 256, 4
 
 
+def _conv_fns(L, stream, new):
+    """(conv, hconv) launchers bound to one HIP stream; hconv = per-sample rows (split-K head GEMMs)."""
+    def conv(pc: PackedConv, x, B, H, W, act=ACT_NONE, res=None, out=None, **kw):
+        Ho = (H + 2 * pc.pad - pc.KH) // pc.stride + 1
+        Wo = (W + 2 * pc.pad - pc.KW) // pc.stride + 1
+        out = out if out is not None else new(B, Ho, Wo, pc.Cout)
+        HandsLight._conv(L, pc, x, B, H, W, out, act, stream, res=res, **kw)
+        return out, Ho, Wo
+
+    return conv, (lambda *a, **kw: conv(*a, splitk=True, **kw))
+
+
 class HandOccNet(nn.Module):
     def __init__(self, focal_length=1000.0, img_res=224, args=None, mano_assets=None):
         super().__init__()
@@ -61,6 +73,15 @@ class HandOccNet(nn.Module):
         self._packed = None
         self._packed_dev = None
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_packed())
+
+    chunks = 2   # the 2*bz crops run as this many jobs on separate HIP streams (1 = single stream)
+
+    def _side_stream(self, dev, i):
+        key = ("side_stream", i)
+        st = self.__dict__.setdefault("_streams", {}).get(key)
+        if st is None or st.device != dev:
+            st = self.__dict__["_streams"][key] = torch.cuda.Stream(device=dev)
+        return st
 
     def invalidate_packed(self):
         self._packed = None
@@ -188,15 +209,6 @@ class HandOccNet(nn.Module):
         stream = torch.cuda.current_stream(dev).cuda_stream
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
 
-        def conv(pc: PackedConv, x, B, H, W, act=ACT_NONE, res=None, out=None, **kw):
-            Ho = (H + 2 * pc.pad - pc.KH) // pc.stride + 1
-            Wo = (W + 2 * pc.pad - pc.KW) // pc.stride + 1
-            out = out if out is not None else new(B, Ho, Wo, pc.Cout)
-            HandsLight._conv(L, pc, x, B, H, W, out, act, stream, res=res, **kw)
-            return out, Ho, Wo
-
-        hconv = lambda *a, **kw: conv(*a, splitk=True, **kw)     # per-sample rows: latency-bound head GEMMs
-
         # -- model.py:66-70: resize to 256x256, cat(r, l) -> NHWC4 ---------------------------------
         S = 256
         x4 = new(B2, S, S, 4)
@@ -206,144 +218,183 @@ class HandOccNet(nn.Module):
         # -- KPE embedding (hamer_light/pos_emb.py:28-64, feat_dim 256) ----------------------------
         center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
         corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0)
-        enc = new(B2, P["kpe0"].Cin)
-        check(L.hands_kpe_encode_f32(ptr(center), ptr(corner), ptr(enc), B2, P["kpe0"].Cin, self.n_freq, stream), "kpe")
-        k1, _, _ = conv(P["kpe0"], enc, B2, 1, 1, ACT_RELU)
-        kpe, _, _ = conv(P["kpe2"], k1, B2, 1, 1, ACT_RELU)
-        kpe = kpe.view(B2, CF)
-        # -- LeakyReLU ResNet-50 (backbone.py:44-53) ------------------------------------------------
-        a, H, W = conv(P["stem"], x4, B2, S, S, ACT_LEAKY_RELU)
-        Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
-        cur = new(B2, Hp, Wp, 64)
-        check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(cur), B2, H, W, 64, stream), "maxpool")
-        H, W = Hp, Wp
-        stages = []
-        for blocks in P["layers"]:
-            for e in blocks:
-                t1, _, _ = conv(e["c1"], cur, B2, H, W, ACT_LEAKY_RELU)
-                t2, H2, W2 = conv(e["c2"], t1, B2, H, W, ACT_LEAKY_RELU)
-                ident = conv(e["ds"], cur, B2, H, W)[0] if "ds" in e else cur
-                cur, _, _ = conv(e["c3"], t2, B2, H2, W2, ACT_LEAKY_RELU, res=ident)
-                H, W = H2, W2
-            stages.append((cur, H, W))
-        (c2, h2, w2), (c3, h3, w3), (c4, h4, w4), (c5, h5, w5) = stages
-        # -- FPN top-down (backbone.py:54-62) ------------------------------------------------------
-        def up_add(x, h, w, y, Hh, Ww):
-            out = new(B2, Hh, Ww, CF)
-            check(L.hands_upsample_bilinear_add_f32(ptr(x), ptr(y), ptr(out), B2, h, w, Hh, Ww, CF, stream), "up_add")
-            return out
-        p5, _, _ = conv(P["toplayer"], c5, B2, h5, w5)
-        p4 = up_add(p5, h5, w5, conv(P["latlayer1"], c4, B2, h4, w4)[0], h4, w4)
-        p3 = up_add(p4, h4, w4, conv(P["latlayer2"], c3, B2, h3, w3)[0], h3, w3)
-        p2 = up_add(p3, h3, w3, conv(P["latlayer3"], c2, B2, h2, w2)[0], h2, w2)
-        p2, _, _ = conv(P["smooth3"], p2, B2, h2, w2)          # smooth2(p3) of the reference is dead code
-        Hf, Wf = h2 // 2, w2 // 2
-        assert Hf * Wf == NTOK
-        pooled = new(B2, Hf, Wf, CF)
-        check(L.hands_pool2x2_nhwc_f32(ptr(p2), ptr(pooled), B2, h2, w2, CF, 0, stream), "avgpool")
-        # -- SpatialGate (cbam.py:72-82) ------------------------------------------------------------
-        npix = B2 * NTOK
-        comp = new(npix, 4)
-        check(L.hands_channel_pool_f32(ptr(pooled), ptr(comp), npix, CF, stream), "channel_pool")
-        logit, _, _ = conv(P["gate"], comp, B2, Hf, Wf)
-        primary, secondary = new(npix, CF), new(npix, CF)
+
+        conv, hconv = _conv_fns(L, stream, new)
+
+        def pipeline(x4, center, corner, B2, stream):
+            """Everything per crop, from the NHWC image to the 112-vector of the regressor; rows are
+            independent, so the 2*bz crops may be cut into chunks that run on separate HIP streams."""
+            npix = B2 * NTOK
+            conv, hconv = _conv_fns(L, stream, new)
+            enc = new(B2, P["kpe0"].Cin)
+            check(L.hands_kpe_encode_f32(ptr(center), ptr(corner), ptr(enc), B2, P["kpe0"].Cin, self.n_freq, stream), "kpe")
+            k1, _, _ = conv(P["kpe0"], enc, B2, 1, 1, ACT_RELU)
+            kpe, _, _ = conv(P["kpe2"], k1, B2, 1, 1, ACT_RELU)
+            kpe = kpe.view(B2, CF)
+            # -- LeakyReLU ResNet-50 (backbone.py:44-53) ------------------------------------------------
+            a, H, W = conv(P["stem"], x4, B2, S, S, ACT_LEAKY_RELU)
+            Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+            cur = new(B2, Hp, Wp, 64)
+            check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(cur), B2, H, W, 64, stream), "maxpool")
+            H, W = Hp, Wp
+            stages = []
+            for blocks in P["layers"]:
+                for e in blocks:
+                    t1, _, _ = conv(e["c1"], cur, B2, H, W, ACT_LEAKY_RELU)
+                    t2, H2, W2 = conv(e["c2"], t1, B2, H, W, ACT_LEAKY_RELU)
+                    ident = conv(e["ds"], cur, B2, H, W)[0] if "ds" in e else cur
+                    cur, _, _ = conv(e["c3"], t2, B2, H2, W2, ACT_LEAKY_RELU, res=ident)
+                    H, W = H2, W2
+                stages.append((cur, H, W))
+            (c2, h2, w2), (c3, h3, w3), (c4, h4, w4), (c5, h5, w5) = stages
+            # -- FPN top-down (backbone.py:54-62) ------------------------------------------------------
+            def up_add(x, h, w, y, Hh, Ww):
+                out = new(B2, Hh, Ww, CF)
+                check(L.hands_upsample_bilinear_add_f32(ptr(x), ptr(y), ptr(out), B2, h, w, Hh, Ww, CF, stream), "up_add")
+                return out
+            p5, _, _ = conv(P["toplayer"], c5, B2, h5, w5)
+            p4 = up_add(p5, h5, w5, conv(P["latlayer1"], c4, B2, h4, w4)[0], h4, w4)
+            p3 = up_add(p4, h4, w4, conv(P["latlayer2"], c3, B2, h3, w3)[0], h3, w3)
+            p2 = up_add(p3, h3, w3, conv(P["latlayer3"], c2, B2, h2, w2)[0], h2, w2)
+            p2, _, _ = conv(P["smooth3"], p2, B2, h2, w2)          # smooth2(p3) of the reference is dead code
+            Hf, Wf = h2 // 2, w2 // 2
+            assert Hf * Wf == NTOK
+            pooled = new(B2, Hf, Wf, CF)
+            check(L.hands_pool2x2_nhwc_f32(ptr(p2), ptr(pooled), B2, h2, w2, CF, 0, stream), "avgpool")
+            # -- SpatialGate (cbam.py:72-82) ------------------------------------------------------------
+            npix = B2 * NTOK
+            comp = new(npix, 4)
+            check(L.hands_channel_pool_f32(ptr(pooled), ptr(comp), npix, CF, stream), "channel_pool")
+            logit, _, _ = conv(P["gate"], comp, B2, Hf, Wf)
+            primary, secondary = new(npix, CF), new(npix, CF)
+            check(L.hands_gate_apply_f32(ptr(pooled), ptr(logit), 4, ptr(primary), ptr(secondary), npix, CF, stream), "gate")
+
+            # -- FIT / SET (transformer.py:26-35,117-157) ------------------------------------------------
+            scale = float((CF // HEADS) ** -0.5)
+
+            def block(e, query, key, injection):
+                qe, ke = new(npix, CF), new(npix, CF)
+                check(L.hands_add_embed2_f32(ptr(query), ptr(key), ptr(e["qemb"]), ptr(e["kemb"]), ptr(kpe), ptr(qe), ptr(ke),
+                                             B2, NTOK, CF, stream), "add_embed")
+                v = conv(e["v"], key, npix, 1, 1)[0]
+                q = conv(e["q"], qe, npix, 1, 1)[0]
+                k = conv(e["k"], ke, npix, 1, 1)[0]
+                x = new(npix, CF)
+                if injection:
+                    q2 = conv(e["q2"], qe, npix, 1, 1)[0]
+                    k2 = conv(e["k2"], ke, npix, 1, 1)[0]
+                    k2sum = new(B2, CF)
+                    check(L.hands_token_sum_f32(ptr(k2), ptr(k2sum), B2, NTOK, CF, stream), "token_sum")
+                    check(L.hands_flash_attention_f32(ptr(q), ptr(k), ptr(v), ptr(q2), ptr(k2sum), None, ptr(x), B2, NTOK,
+                                                      HEADS, CF // HEADS, scale, stream), "flash_attention")
+                else:
+                    check(L.hands_flash_attention_f32(ptr(q), ptr(k), ptr(v), None, None, ptr(query), ptr(x), B2, NTOK,
+                                                      HEADS, CF // HEADS, scale, stream), "flash_attention")
+                y = new(npix, CF)
+                check(L.hands_layernorm_f32(ptr(x), ptr(e["n2"][0]), ptr(e["n2"][1]), ptr(y), None, 1, npix, CF, 1e-5, stream),
+                      "layernorm")
+                hdn = conv(e["fc1"], y, npix, 1, 1, ACT_GELU)[0]
+                conv(e["fc2"], hdn, npix, 1, 1, res=x, out=x)
+                return x
+
+            out = secondary
+            for e in P["FIT"]:
+                out = block(e, out, primary, True)
+            cat = torch.cat([primary.view(npix, CF), out.view(npix, CF)], dim=1)          # (npix, 512)
+            c20 = conv(P["fit_c20"], cat, B2, Hf, Wf)[0]
+            c10 = conv(P["fit_c10"], cat, B2, Hf, Wf, ACT_RELU)[0]
+            feats = conv(P["fit_c12"], c10, B2, Hf, Wf, res=c20)[0].view(npix, CF)
+            if dbg is not None:
+                dbg.update(primary=primary, secondary=secondary, fit=feats, c5=c5, pooled=pooled)
+            key = feats
+            out = feats
+            for e in P["SET"]:
+                out = block(e, out, key, False)
+            feats = new(npix, CF)
+            check(L.hands_add_rowvec_f32(ptr(out), ptr(kpe), ptr(feats), B2, NTOK, CF, stream), "add_kpe")   # model.py:88-89
+
+            # -- regressor (hand_head.py, mano_head.py:190-207) -------------------------------------------
+            def unit(u, x, H, W):
+                n = B2 * H * W
+                t0 = new(n, CF)
+                check(L.hands_bn_leaky_f32(ptr(x), ptr(u["pre"][0]), ptr(u["pre"][1]), ptr(t0), n, CF, stream), "bn_leaky")
+                t1 = conv(u["c1"], t0, B2, H, W, ACT_LEAKY_RELU)[0]
+                t2 = conv(u["c2"], t1, B2, H, W, ACT_LEAKY_RELU)[0]
+                return conv(u["c3"], t2, B2, H, W, res=x)[0]
+
+            def pool(x, H, W, mode):
+                o = new(B2, H // 2, W // 2, CF)
+                check(L.hands_pool2x2_nhwc_f32(ptr(x), ptr(o), B2, H, W, CF, mode, stream), "pool2x2")
+                return o
+
+            def hourglass(n, x, H, W):                                  # hand_head.py:217-235
+                lv = P["hg"][n - 1]
+                up1 = unit(lv[0], x, H, W)
+                low1 = unit(lv[1], pool(x, H, W, 1), H // 2, W // 2)
+                low2 = hourglass(n - 1, low1, H // 2, W // 2) if n > 1 else unit(lv[3], low1, H // 2, W // 2)
+                low3 = unit(lv[2], low2, H // 2, W // 2)
+                o = new(B2, H, W, CF)
+                check(L.hands_upsample_nearest2x_add_f32(ptr(low3), ptr(up1), ptr(o), B2, H // 2, W // 2, CF, stream), "up2x")
+                return o
+
+            if dbg is not None:
+                dbg["set"] = out
+            y = hourglass(4, feats, Hf, Wf)
+            if dbg is not None:
+                dbg["hourglass"] = y
+            y = unit(P["res"], y, Hf, Wf)
+            y = conv(P["fc"], y, B2, Hf, Wf, ACT_LEAKY_RELU)[0]
+            lat = conv(P["score"], y, B2, Hf, Wf)[0]                     # (B2,32,32,24): 21 joints + pad
+            heat = new(npix, 32)
+            check(L.hands_spatial_softmax_f32(ptr(lat), P["score"].Cout, ptr(P["betas"]), ptr(heat), 32, B2, NTOK, 21, stream),
+                  "spatial_softmax")
+            if dbg is not None:
+                dbg.update(heat=heat, lat=lat)
+            hm = conv(P["hm_conv"], heat, B2, Hf, Wf)[0]
+            x = conv(P["enc_conv"], y, B2, Hf, Wf, res=hm)[0]
+            H, W = Hf, Wf
+            for i in range(4):
+                x = unit(P["enc"][2 * i], x, H, W)
+                x = unit(P["enc"][2 * i + 1], x, H, W)
+                x = pool(x, H, W, 1)
+                H, W = H // 2, W // 2
+            if dbg is not None:
+                dbg["enc"] = x
+            f = hconv(P["base0"], x, B2, 1, 1, ACT_LEAKY_RELU)[0]         # x: (B2,2,2,256) read as (B2,1024)
+            f = hconv(P["base2"], f, B2, 1, 1, ACT_LEAKY_RELU)[0]
+            pred = hconv(P["regs"], f, B2, 1, 1)[0].view(B2, 112)
+            return pred
+
         dbg = self.__dict__.get("_debug")
-        check(L.hands_gate_apply_f32(ptr(pooled), ptr(logit), 4, ptr(primary), ptr(secondary), npix, CF, stream), "gate")
-
-        # -- FIT / SET (transformer.py:26-35,117-157) ------------------------------------------------
-        scale = float((CF // HEADS) ** -0.5)
-
-        def block(e, query, key, injection):
-            qe, ke = new(npix, CF), new(npix, CF)
-            check(L.hands_add_embed2_f32(ptr(query), ptr(key), ptr(e["qemb"]), ptr(e["kemb"]), ptr(kpe), ptr(qe), ptr(ke),
-                                         B2, NTOK, CF, stream), "add_embed")
-            v = conv(e["v"], key, npix, 1, 1)[0]
-            q = conv(e["q"], qe, npix, 1, 1)[0]
-            k = conv(e["k"], ke, npix, 1, 1)[0]
-            x = new(npix, CF)
-            if injection:
-                q2 = conv(e["q2"], qe, npix, 1, 1)[0]
-                k2 = conv(e["k2"], ke, npix, 1, 1)[0]
-                k2sum = new(B2, CF)
-                check(L.hands_token_sum_f32(ptr(k2), ptr(k2sum), B2, NTOK, CF, stream), "token_sum")
-                check(L.hands_flash_attention_f32(ptr(q), ptr(k), ptr(v), ptr(q2), ptr(k2sum), None, ptr(x), B2, NTOK,
-                                                  HEADS, CF // HEADS, scale, stream), "flash_attention")
-            else:
-                check(L.hands_flash_attention_f32(ptr(q), ptr(k), ptr(v), None, None, ptr(query), ptr(x), B2, NTOK,
-                                                  HEADS, CF // HEADS, scale, stream), "flash_attention")
-            y = new(npix, CF)
-            check(L.hands_layernorm_f32(ptr(x), ptr(e["n2"][0]), ptr(e["n2"][1]), ptr(y), None, 1, npix, CF, 1e-5, stream),
-                  "layernorm")
-            hdn = conv(e["fc1"], y, npix, 1, 1, ACT_GELU)[0]
-            conv(e["fc2"], hdn, npix, 1, 1, res=x, out=x)
-            return x
-
-        out = secondary
-        for e in P["FIT"]:
-            out = block(e, out, primary, True)
-        cat = torch.cat([primary.view(npix, CF), out.view(npix, CF)], dim=1)          # (npix, 512)
-        c20 = conv(P["fit_c20"], cat, B2, Hf, Wf)[0]
-        c10 = conv(P["fit_c10"], cat, B2, Hf, Wf, ACT_RELU)[0]
-        feats = conv(P["fit_c12"], c10, B2, Hf, Wf, res=c20)[0].view(npix, CF)
-        if dbg is not None:
-            dbg.update(primary=primary, secondary=secondary, fit=feats, c5=c5, pooled=pooled)
-        key = feats
-        out = feats
-        for e in P["SET"]:
-            out = block(e, out, key, False)
-        feats = new(npix, CF)
-        check(L.hands_add_rowvec_f32(ptr(out), ptr(kpe), ptr(feats), B2, NTOK, CF, stream), "add_kpe")   # model.py:88-89
-
-        # -- regressor (hand_head.py, mano_head.py:190-207) -------------------------------------------
-        def unit(u, x, H, W):
-            n = B2 * H * W
-            t0 = new(n, CF)
-            check(L.hands_bn_leaky_f32(ptr(x), ptr(u["pre"][0]), ptr(u["pre"][1]), ptr(t0), n, CF, stream), "bn_leaky")
-            t1 = conv(u["c1"], t0, B2, H, W, ACT_LEAKY_RELU)[0]
-            t2 = conv(u["c2"], t1, B2, H, W, ACT_LEAKY_RELU)[0]
-            return conv(u["c3"], t2, B2, H, W, res=x)[0]
-
-        def pool(x, H, W, mode):
-            o = new(B2, H // 2, W // 2, CF)
-            check(L.hands_pool2x2_nhwc_f32(ptr(x), ptr(o), B2, H, W, CF, mode, stream), "pool2x2")
-            return o
-
-        def hourglass(n, x, H, W):                                  # hand_head.py:217-235
-            lv = P["hg"][n - 1]
-            up1 = unit(lv[0], x, H, W)
-            low1 = unit(lv[1], pool(x, H, W, 1), H // 2, W // 2)
-            low2 = hourglass(n - 1, low1, H // 2, W // 2) if n > 1 else unit(lv[3], low1, H // 2, W // 2)
-            low3 = unit(lv[2], low2, H // 2, W // 2)
-            o = new(B2, H, W, CF)
-            check(L.hands_upsample_nearest2x_add_f32(ptr(low3), ptr(up1), ptr(o), B2, H // 2, W // 2, CF, stream), "up2x")
-            return o
-
-        if dbg is not None:
-            dbg["set"] = out
-        y = hourglass(4, feats, Hf, Wf)
-        if dbg is not None:
-            dbg["hourglass"] = y
-        y = unit(P["res"], y, Hf, Wf)
-        y = conv(P["fc"], y, B2, Hf, Wf, ACT_LEAKY_RELU)[0]
-        lat = conv(P["score"], y, B2, Hf, Wf)[0]                     # (B2,32,32,24): 21 joints + pad
-        heat = new(npix, 32)
-        check(L.hands_spatial_softmax_f32(ptr(lat), P["score"].Cout, ptr(P["betas"]), ptr(heat), 32, B2, NTOK, 21, stream),
-              "spatial_softmax")
-        if dbg is not None:
-            dbg.update(heat=heat, lat=lat)
-        hm = conv(P["hm_conv"], heat, B2, Hf, Wf)[0]
-        x = conv(P["enc_conv"], y, B2, Hf, Wf, res=hm)[0]
-        H, W = Hf, Wf
-        for i in range(4):
-            x = unit(P["enc"][2 * i], x, H, W)
-            x = unit(P["enc"][2 * i + 1], x, H, W)
-            x = pool(x, H, W, 1)
-            H, W = H // 2, W // 2
-        if dbg is not None:
-            dbg["enc"] = x
-        f = hconv(P["base0"], x, B2, 1, 1, ACT_LEAKY_RELU)[0]         # x: (B2,2,2,256) read as (B2,1024)
-        f = hconv(P["base2"], f, B2, 1, 1, ACT_LEAKY_RELU)[0]
-        pred = hconv(P["regs"], f, B2, 1, 1)[0].view(B2, 112)
+        main = torch.cuda.current_stream(dev)
+        # measured (bz=32 -> 64 crops): 2 chunks without split-K lose 8 % (smaller launches), with
+        # latency_mode they gain 4 %; at 512 crops they gain 3 %
+        nch = HandOccNet.chunks if (dbg is None and HandsLight.overlap_trunks and (B2 >= 128 or HandsLight.latency_mode)) else 1
+        nch = max(1, min(nch, B2))
+        if nch == 1:
+            pred = pipeline(x4, center, corner, B2, stream)
+        else:
+            # chunks of crops on separate streams: a launch is a few hundred workgroups on 256 CUs, and
+            # the other chunk's workgroups fill its tail (same idea as HandsLight.trunk_chunks)
+            ev0 = torch.cuda.Event()
+            ev0.record(main)
+            parts, done = [], []
+            for ci in range(nch):
+                lo, hi = ci * B2 // nch, (ci + 1) * B2 // nch
+                st = main if ci == nch - 1 else self._side_stream(dev, ci)
+                if st is not main:
+                    st.wait_event(ev0)
+                with torch.cuda.stream(st):
+                    pc_ = pipeline(x4[lo:hi], center[lo:hi].contiguous(), corner[lo:hi].contiguous(), hi - lo, st.cuda_stream)
+                if st is not main:
+                    pc_.record_stream(main)
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    done.append(ev)
+                parts.append(pc_)
+            for ev in done:
+                main.wait_event(ev)
+            pred = torch.cat(parts, 0)
         rot = new(B2, 16, 3, 3)
         check(L.hands_rot6d_to_matrix_cols_f32(ptr(pred), 112, ptr(rot), B2, stream), "rot6d_cols")
         if dbg is not None:
