@@ -11,6 +11,8 @@ from .mano import ManoAsset, synthetic_mano_asset, build_mano_asset  # noqa: F40
 from .weights import apply_recipe, synthetic_inputs  # noqa: F401
 from .frontend import HandsFrontEnd  # noqa: F401
 from .graph import GraphedForward  # noqa: F401
+from .wrapper import HandsWrapper, HaMeRWrapper, HandOccNetWrapper  # noqa: F401
 
 __all__ = ["HandsLight", "DEFAULT_ARGS", "HAMER", "HAMER_DEFAULT_ARGS", "HandOccNet", "HANDOCC_DEFAULT_ARGS", "xdict", "prefix_dict", "ManoAsset", "synthetic_mano_asset",
-           "build_mano_asset", "apply_recipe", "synthetic_inputs"]
+           "build_mano_asset", "apply_recipe", "synthetic_inputs", "HandsFrontEnd", "GraphedForward", "HandsWrapper",
+           "HaMeRWrapper", "HandOccNetWrapper"]

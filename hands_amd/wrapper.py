@@ -121,3 +121,27 @@ class HandsWrapper(nn.Module):
         if mode == "extract":
             return merged()
         return out_dict, {}
+
+
+class HaMeRWrapper(HandsWrapper):
+    """src/models/hamer_light/wrapper.py:5-19: the same shell around ``HAMER``."""
+
+    def __init__(self, args=None, push_images_fn=None, model=None):
+        from .hamer import HAMER, HAMER_DEFAULT_ARGS
+        args = args if args is not None else HAMER_DEFAULT_ARGS
+        get = args.get if hasattr(args, "get") else (lambda k, d=None: getattr(args, k, d))
+        if model is None:
+            model = HAMER(focal_length=get("focal_length", 1000.0), img_res=get("img_res", 224), args=args)
+        super().__init__(args, push_images_fn, model=model)
+
+
+class HandOccNetWrapper(HandsWrapper):
+    """src/models/handoccnet_light/wrapper.py:5-19: the same shell around ``HandOccNet``."""
+
+    def __init__(self, args=None, push_images_fn=None, model=None):
+        from .handoccnet import HANDOCC_DEFAULT_ARGS, HandOccNet
+        args = args if args is not None else HANDOCC_DEFAULT_ARGS
+        get = args.get if hasattr(args, "get") else (lambda k, d=None: getattr(args, k, d))
+        if model is None:
+            model = HandOccNet(focal_length=get("focal_length", 1000.0), img_res=get("img_res", 224), args=args)
+        super().__init__(args, push_images_fn, model=model)

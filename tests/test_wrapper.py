@@ -64,3 +64,21 @@ def test_wrapper_test_mode_on_device(golden_dir, recipe_model):
     assert torch.allclose(ex["pred.mano.j2d.r"], 0.5 * 224 * (pr + 1), atol=1e-4)
     with pytest.raises(NotImplementedError):
         w.forward(inputs, targets, meta, "train")
+
+
+@pytest.mark.gpu
+def test_handoccnet_wrapper_inference():
+    """HandOccNetWrapper (src/models/handoccnet_light/wrapper.py:5-19): same shell, other model."""
+    import hands_amd
+    from hands_amd.weights import synthetic_inputs
+    from hands_amd.wrapper import HandOccNetWrapper, HaMeRWrapper, HandsWrapper
+    assert issubclass(HaMeRWrapper, HandsWrapper)
+    w = HandOccNetWrapper()
+    hands_amd.apply_recipe(w.model)
+    w = w.to("cuda").eval()
+    inputs, meta = synthetic_inputs(2, 0, device="cuda")
+    out = w.inference(inputs, meta)
+    direct = w.model(inputs, meta)
+    assert out["pred.mano.vertices.r"].device.type == "cpu" and out["pred.mano.vertices.r"].shape == (2, 778, 3)
+    assert torch.equal(out["pred.mano.vertices.l"], direct["mano.vertices.l"].cpu())
+    assert "inputs.r_img" in out and "meta_info.intrinsics" in out
