@@ -58,6 +58,8 @@ struct ConvArgs {
   int in_ps, out_ps, res_ps;
   int relu;
   int nblk_m, nblk_n;
+  const float* __restrict__ in2;   // MODE 2: second source, 1x1 sampled with stride2
+  int K0, H2, W2, stride2, in2_ps;
   int ksplit;         // > 1: deterministic split-K, grid = tiles * ksplit, raw partial sums to `partial`
   float* partial;     // [ksplit][M][part_ps]
   int part_ps;
@@ -72,8 +74,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
-template <int WAVES_M, int WAVES_N, bool STEM>
+// MODE 0: any convolution with Cin % 16 == 0; 1: the stem (Cin == 4, one filter tap per 16-byte chunk);
+// 2: two 1x1 convolutions summed into one output (k < K0 from `in`, the rest from `in2` sampled with
+//    its own stride) -- the last conv of a bottleneck fused with the block's downsample branch.
+template <int WAVES_M, int WAVES_N, int MODE>
 __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
+  constexpr bool STEM = MODE == 1;
+  constexpr bool DUAL = MODE == 2;
   constexpr int BM = 64 * WAVES_M;
   constexpr int BN = 64 * WAVES_N;
   constexpr int A_ROWS = BM / 64;   // activation rows staged per thread
@@ -102,6 +109,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   int x_base[A_ROWS];     // float offset of pixel (b, ho*s-pad, wo*s-pad) channel 0 (may be "negative")
   int x_hi0[A_ROWS], x_wi0[A_ROWS];
   bool x_ok[A_ROWS];
+  int x_base2[DUAL ? A_ROWS : 1];
   const int HoWo = a.Ho * a.Wo;
 #pragma unroll
   for (int i = 0; i < A_ROWS; ++i) {
@@ -115,6 +123,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
     x_hi0[i] = ho * a.stride - a.pad;
     x_wi0[i] = wo * a.stride - a.pad;
     x_base[i] = ((b * a.H + x_hi0[i]) * a.W + x_wi0[i]) * a.in_ps;
+    if constexpr (DUAL) x_base2[i] = ((b * a.H2 + ho * a.stride2) * a.W2 + wo * a.stride2) * a.in2_ps;
   }
   const float* wrow[W_ROWS];
 #pragma unroll
@@ -125,6 +134,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   // k-step state (wave-uniform for the regular path)
   int kh = 0, kw = 0, c0 = 0;
   const int ntaps = a.KH * a.KW;
+  const float* dual_src = a.in;
 
 #define LOAD_TILES(KT)                                                                              \
   do {                                                                                              \
@@ -139,6 +149,15 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
                         (unsigned)(x_wi0[i] + tkw) < (unsigned)a.W;                                 \
         xr[i] = ok ? *reinterpret_cast<const float4*>(a.in + (x_base[i] + toff))                    \
                    : make_float4(0.f, 0.f, 0.f, 0.f);                                               \
+      }                                                                                             \
+    } else if constexpr (DUAL) {                                                                    \
+      if ((KT) * BK == a.K0) {               /* wave-uniform: switch to the second source once */   \
+        dual_src = a.in2 - a.K0;                                                                    \
+        _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) x_base[i] = x_base2[i];                  \
+      }                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) {                                          \
+        xr[i] = x_ok[i] ? *reinterpret_cast<const float4*>(dual_src + (x_base[i] + (KT) * BK + chunk * 4)) \
+                        : make_float4(0.f, 0.f, 0.f, 0.f);                                          \
       }                                                                                             \
     } else {                                                                                        \
       const int toff = (kh * a.W + kw) * a.in_ps + c0 + chunk * 4;                                  \
@@ -177,7 +196,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   const int nk_all = a.Kpad / BK;
   const int kt0 = a.ksplit > 1 ? (int)((long long)split * nk_all / a.ksplit) : 0;
   const int kt1 = a.ksplit > 1 ? (int)((long long)(split + 1) * nk_all / a.ksplit) : nk_all;
-  if constexpr (!STEM) {
+  if constexpr (MODE == 0) {
     if (a.ksplit > 1) {
       const int tap0 = (kt0 * BK) / a.Cin;
       c0 = kt0 * BK - tap0 * a.Cin;
@@ -278,14 +297,14 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
 #undef STORE_TILES
 }
 
-template <int WAVES_M, int WAVES_N, bool STEM>
+template <int WAVES_M, int WAVES_N, int MODE>
 int launch(ConvArgs& a, hipStream_t stream) {
   constexpr int BM = 64 * WAVES_M, BN = 64 * WAVES_N;
   a.nblk_m = (a.M + BM - 1) / BM;
   a.nblk_n = (a.N + BN - 1) / BN;
   const long long nwg = (long long)a.nblk_m * a.nblk_n * (a.ksplit > 1 ? a.ksplit : 1);
   if (nwg <= 0 || nwg > 0x7fffffffLL) return HANDS_EINVAL;
-  hipLaunchKernelGGL((conv_igemm_f32_kernel<WAVES_M, WAVES_N, STEM>), dim3((unsigned)nwg), dim3(256), 0,
+  hipLaunchKernelGGL((conv_igemm_f32_kernel<WAVES_M, WAVES_N, MODE>), dim3((unsigned)nwg), dim3(256), 0,
                      stream, a);
   return (int)hipGetLastError();
 }
@@ -349,9 +368,35 @@ extern "C" int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, 
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
   a.relu = d->act;
   a.ksplit = 1; a.partial = nullptr; a.part_ps = 0;
+  a.in2 = nullptr; a.K0 = 0; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
   hipStream_t s = (hipStream_t)stream;
-  if (stem) return (d->Cout <= 64) ? launch<4, 1, true>(a, s) : launch<2, 2, true>(a, s);
-  return (d->Cout <= 64) ? launch<4, 1, false>(a, s) : launch<2, 2, false>(a, s);
+  if (stem) return (d->Cout <= 64) ? launch<4, 1, 1>(a, s) : launch<2, 2, 1>(a, s);
+  return (d->Cout <= 64) ? launch<4, 1, 0>(a, s) : launch<2, 2, 0>(a, s);
+}
+
+extern "C" int hands_conv1x1_dual_nhwc_f32(const hands_conv_desc* d, const float* in, const float* in2, int Cin2, int H2,
+                                           int W2, int stride2, int in2_pix_stride, const float* w_packed,
+                                           const float* bias, float* out, hands_stream_t stream) {
+  if (!d || !in || !in2 || !w_packed || !bias || !out) return HANDS_EINVAL;
+  if (d->B <= 0 || d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->H != d->Ho || d->W != d->Wo)
+    return HANDS_EINVAL;
+  if (d->Cin % 16 || Cin2 <= 0 || Cin2 % 16 || d->Cout % 4 || d->Kpad != d->Cin + Cin2) return HANDS_EINVAL;
+  if (d->in_pix_stride < d->Cin || in2_pix_stride < Cin2 || d->out_pix_stride < d->Cout || stride2 < 1) return HANDS_EINVAL;
+  if ((d->Ho - 1) * stride2 >= H2 || (d->Wo - 1) * stride2 >= W2) return HANDS_EINVAL;
+  if ((long long)d->B * d->H * d->W * d->in_pix_stride >= (1LL << 31) ||
+      (long long)d->B * H2 * W2 * in2_pix_stride >= (1LL << 31))
+    return HANDS_EINVAL;
+  ConvArgs a;
+  a.in = in; a.w = w_packed; a.bias = bias; a.res = nullptr; a.out = out;
+  a.M = d->B * d->Ho * d->Wo; a.N = d->Cout; a.Kpad = d->Kpad;
+  a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
+  a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0;
+  a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = 0;
+  a.relu = d->act;
+  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0;
+  a.in2 = in2; a.K0 = d->Cin; a.H2 = H2; a.W2 = W2; a.stride2 = stride2; a.in2_ps = in2_pix_stride;
+  hipStream_t s = (hipStream_t)stream;
+  return (d->Cout <= 64) ? launch<4, 1, 2>(a, s) : launch<2, 2, 2>(a, s);
 }
 
 extern "C" int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
@@ -377,10 +422,11 @@ extern "C" int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const fl
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
   a.relu = HANDS_ACT_NONE;
   a.ksplit = S; a.partial = workspace; a.part_ps = part_ps;
+  a.in2 = nullptr; a.K0 = 0; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (stem) rc = (d->Cout <= 64) ? launch<4, 1, true>(a, s) : launch<2, 2, true>(a, s);
-  else rc = (d->Cout <= 64) ? launch<4, 1, false>(a, s) : launch<2, 2, false>(a, s);
+  if (stem) rc = (d->Cout <= 64) ? launch<4, 1, 1>(a, s) : launch<2, 2, 1>(a, s);
+  else rc = (d->Cout <= 64) ? launch<4, 1, 0>(a, s) : launch<2, 2, 0>(a, s);
   if (rc) return rc;
   const long long total = M * (d->Cout / 4);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(hands_grid_1d(total, 256)), dim3(256), 0, s, workspace, S, (int)M,

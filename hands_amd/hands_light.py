@@ -249,6 +249,10 @@ class HandsLight(nn.Module):
                 if blk.downsample is not None:
                     w, b = fold_bn(cpu(blk.downsample[0].weight), *bnp(blk.downsample[1]))
                     e["ds"] = pack_conv(w, b, blk.stride, 0, dev)
+                    # conv3 + downsample as ONE GEMM over K = planes + inplanes (hands_conv1x1_dual_nhwc_f32)
+                    w3, b3 = fold_bn(cpu(blk.conv3.weight), *bnp(blk.bn3))
+                    e["c3ds"] = pack_conv(torch.cat([w3.double(), w.double()], 1), b3.double() + b.double(), 1, 0, dev)
+                    e["c3ds_split"] = (w3.shape[1], w.shape[1], blk.stride)
                 blocks.append(e)
         P["blocks"] = blocks
         return P
@@ -370,6 +374,21 @@ class HandsLight(nn.Module):
             hook("end", pc, B * Ho * Wo, stream, res is not None)
         return Ho, Wo
 
+    fuse_downsample = True  # first block of each stage: conv3 + downsample + add + ReLU as one two-source GEMM
+
+    @staticmethod
+    def _conv_dual(L, pc: PackedConv, split, x, x2, B, Ho, Wo, H2, W2, out, stream):
+        """relu(conv3(x) + downsample(x2)) (resnet.py:146-154) with the identity never materialised."""
+        K0, K1, stride2 = split
+        d = ConvDesc(B, Ho, Wo, K0, Ho, Wo, pc.Cout, 1, 1, 1, 0, K0, pc.Cout, 0, pc.Kpad, 1)
+        hook = HandsLight.conv_hook
+        if hook is not None:
+            hook("begin", pc, B * Ho * Wo, stream, False)
+        check(L.hands_conv1x1_dual_nhwc_f32(C.byref(d), ptr(x), ptr(x2), K1, H2, W2, stride2, K1, ptr(pc.w), ptr(pc.bias),
+                                            ptr(out), stream), "hands_conv1x1_dual_nhwc_f32")
+        if hook is not None:
+            hook("end", pc, B * Ho * Wo, stream, False)
+
     def _trunk(self, L, P, x4, B, res_in, stream, tag, cap_B, out=None, x_off=0, out_off=0):
         """ResNet-50 trunk on an NHWC4 batch; returns (B,7,7,2048) features (flat tensor)."""
         dev = x4.device
@@ -387,15 +406,18 @@ class HandsLight(nn.Module):
         for i, e in enumerate(P["blocks"]):
             self._conv(L, e["c1"], cur, B, H, W, t1, True, stream)
             H2, W2 = self._conv(L, e["c2"], t1, B, H, W, t2, True, stream)
-            if "ds" in e:
-                self._conv(L, e["ds"], cur, B, H, W, ds, False, stream)
-                ident = ds
-            else:
-                ident = cur
             last = i + 1 == nblk
             dst = nxt if not last else (out if out is not None else
                                         self._buf("feat_" + tag, B * H2 * W2 * e["c3"].Cout, dev))
-            self._conv(L, e["c3"], t2, B, H2, W2, dst, True, stream, res=ident, out_off=out_off if last else 0)
+            if "ds" in e and HandsLight.fuse_downsample:
+                self._conv_dual(L, e["c3ds"], e["c3ds_split"], t2, cur, B, H2, W2, H, W, dst, stream)
+            else:
+                if "ds" in e:
+                    self._conv(L, e["ds"], cur, B, H, W, ds, False, stream)
+                    ident = ds
+                else:
+                    ident = cur
+                self._conv(L, e["c3"], t2, B, H2, W2, dst, True, stream, res=ident, out_off=out_off if last else 0)
             H, W = H2, W2
             cur, nxt = dst, cur
             if i + 1 == nblk:

@@ -87,6 +87,17 @@ int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const float* in, co
                                    const float* bias, const float* residual, float* out, int S,
                                    float* workspace, long long workspace_floats, hands_stream_t stream);
 
+/* Two 1x1 convolutions summed into one output: out = act(W0 * in + W1 * in2[stride2-sampled] + bias).
+ * `d` describes the first one (stride 1, H = Ho, W = Wo, Cin = K0) with Kpad = K0 + Cin2; the packed
+ * weight row is [W0 (K0) | W1 (Cin2)], both with their BatchNorm folded, bias = b0 + b1.  This is the
+ * last convolution of a ResNet bottleneck fused with the block's downsample branch
+ * (src/nets/backbone/resnet.py:134-154: `out = bn3(conv3(out)); identity = downsample(x); out += identity`):
+ * the identity tensor is never written to or re-read from HBM.  in2 is (B, H2, W2, Cin2) with
+ * in2_pix_stride floats per pixel; output pixel (ho, wo) reads in2 pixel (ho*stride2, wo*stride2). */
+int hands_conv1x1_dual_nhwc_f32(const hands_conv_desc* d, const float* in, const float* in2, int Cin2, int H2,
+                                int W2, int stride2, int in2_pix_stride, const float* w_packed,
+                                const float* bias, float* out, hands_stream_t stream);
+
 /* NCHW (B,3,H,W) image batch -> NHWC with C padded to 4 (4th channel = 0).
  * Replaces the implicit layout of inputs["img"|"r_img"|"l_img"] (model.py:188,238-239). */
 int hands_nchw3_to_nhwc4_f32(const float* in, float* out, int B, int H, int W, hands_stream_t stream);

@@ -112,6 +112,29 @@ def test_conv_igemm_latency_mode_split_k(case):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 256, 56, 1), (3, 128, 256, 512, 28, 2), (1, 512, 1024, 2048, 14, 2), (2, 16, 32, 12, 9, 2)])
+def test_conv1x1_dual_vs_torch(case):
+    """relu(conv1x1(x) + conv1x1_stride(x2) + bias): conv3 + downsample of a bottleneck as one GEMM."""
+    from hands_amd.packing import pack_conv
+    B, K0, K1, Cout, Ho, s2 = case
+    g = torch.Generator().manual_seed(sum(case))
+    H2 = Ho * s2 - (s2 - 1) * (case[0] % 2)            # odd input sizes too: (Ho-1)*s2 < H2
+    x = torch.randn(B, K0, Ho, Ho, generator=g)
+    x2 = torch.randn(B, K1, H2, H2, generator=g)
+    w0 = torch.randn(Cout, K0, 1, 1, generator=g) / K0 ** 0.5
+    w1 = torch.randn(Cout, K1, 1, 1, generator=g) / K1 ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv2d(x.double(), w0.double()) + F.conv2d(x2.double(), w1.double(), stride=s2) + bias.double().view(1, -1, 1, 1))
+    pc = pack_conv(torch.cat([w0, w1], 1), bias, 1, 0, DEV)
+    xd, x2d = _nhwc(x).to(DEV).contiguous(), _nhwc(x2).to(DEV).contiguous()
+    out = torch.full((B, Ho, Ho, pc.Cout), float("nan"), device=DEV)
+    HandsLight._conv_dual(_lib.lib(), pc, (K0, K1, s2), xd, x2d, B, Ho, Ho, H2, H2, out, _stream())
+    torch.cuda.synchronize()
+    got = out.cpu().permute(0, 3, 1, 2)[:, :Cout]
+    err = (got.double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
 def test_stem_conv_bn_fold_vs_torch():
     g = torch.Generator().manual_seed(3)
     x = torch.randn(3, 3, 224, 224, generator=g)
