@@ -377,10 +377,10 @@ class HandsLight(nn.Module):
     fuse_downsample = True  # first block of each stage: conv3 + downsample + add + ReLU as one two-source GEMM
 
     @staticmethod
-    def _conv_dual(L, pc: PackedConv, split, x, x2, B, Ho, Wo, H2, W2, out, stream):
-        """relu(conv3(x) + downsample(x2)) (resnet.py:146-154) with the identity never materialised."""
+    def _conv_dual(L, pc: PackedConv, split, x, x2, B, Ho, Wo, H2, W2, out, stream, act=1):
+        """act(conv3(x) + downsample(x2)) (resnet.py:146-154) with the identity never materialised."""
         K0, K1, stride2 = split
-        d = ConvDesc(B, Ho, Wo, K0, Ho, Wo, pc.Cout, 1, 1, 1, 0, K0, pc.Cout, 0, pc.Kpad, 1)
+        d = ConvDesc(B, Ho, Wo, K0, Ho, Wo, pc.Cout, 1, 1, 1, 0, K0, pc.Cout, 0, pc.Kpad, int(act))
         hook = HandsLight.conv_hook
         if hook is not None:
             hook("begin", pc, B * Ho * Wo, stream, False)
