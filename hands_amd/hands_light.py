@@ -338,7 +338,7 @@ class HandsLight(nn.Module):
 
     @staticmethod
     def _conv(L, pc: PackedConv, x, B, H, W, out, relu, stream, res=None, in_ps=None, out_ps=None,
-              res_ps=None, x_off=0, out_off=0, res_off=0, splitk=False):
+              res_ps=None, x_off=0, out_off=0, res_off=0, splitk=False, splitk_n=0):
         Ho = (H + 2 * pc.pad - pc.KH) // pc.stride + 1
         Wo = (W + 2 * pc.pad - pc.KW) // pc.stride + 1
         d = ConvDesc(B, H, W, pc.Cin, Ho, Wo, pc.Cout, pc.KH, pc.KW, pc.stride, pc.pad,
@@ -351,6 +351,8 @@ class HandsLight(nn.Module):
         # split-K only where the caller says the rows are per-SAMPLE (head MLPs): token / pixel GEMMs
         # would cross the library's row threshold between batch sizes and lose bit-reproducibility
         S = L.hands_conv2d_splitk_factor(C.byref(d)) if (splitk and HandsLight.use_splitk) else 1
+        if splitk_n > 1 and HandsLight.use_splitk:
+            S = splitk_n      # call-site constant: the summation order stays independent of the batch size
         if HandsLight.latency_mode:
             # small-batch serving: a layer with a handful of output tiles walks a K of 2304-4608 serially
             # on a few CUs; cut K so that ~256 workgroups exist, at least 8 k-steps (128 floats) per slice
@@ -504,7 +506,7 @@ class HandsLight(nn.Module):
         f2 = buf("fc2", B2 * (fh - 2) * (fw - 2) * 512)
         h2, w2 = self._conv(L, P["fc2"], f1, B2, fh, fw, f2, True, stream)
         f3 = buf("fc3", B2 * (h2 - 2) * (w2 - 2) * 256)
-        h3, w3 = self._conv(L, P["fc4"], f2, B2, h2, w2, f3, True, stream)
+        h3, w3 = self._conv(L, P["fc4"], f2, B2, h2, w2, f3, True, stream, splitk_n=8)   # 3x3 output map: 72 tiles at bz=256, K=4608
         assert h3 * w3 * 256 == P["fc7"].Cin
         ld = F + HMR_VEC
         state = buf("state", B2 * ld)
