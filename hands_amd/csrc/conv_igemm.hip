@@ -368,9 +368,12 @@ extern "C" int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, 
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
   a.relu = d->act;
   a.ksplit = 1; a.partial = nullptr; a.part_ps = 0;
-  a.in2 = nullptr; a.K0 = 0; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
+  a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
   hipStream_t s = (hipStream_t)stream;
   if (stem) return (d->Cout <= 64) ? launch<4, 1, 1>(a, s) : launch<2, 2, 1>(a, s);
+  // pointwise layers (1x1, no padding; any stride) take the two-source instantiation with the switch
+  // point out of reach: no tap state and no bounds checks in the k-loop
+  if (d->KH == 1 && d->KW == 1 && d->pad == 0) return (d->Cout <= 64) ? launch<4, 1, 2>(a, s) : launch<2, 2, 2>(a, s);
   return (d->Cout <= 64) ? launch<4, 1, 0>(a, s) : launch<2, 2, 0>(a, s);
 }
 
@@ -422,10 +425,11 @@ extern "C" int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const fl
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
   a.relu = HANDS_ACT_NONE;
   a.ksplit = S; a.partial = workspace; a.part_ps = part_ps;
-  a.in2 = nullptr; a.K0 = 0; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
+  a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (stem) rc = (d->Cout <= 64) ? launch<4, 1, 1>(a, s) : launch<2, 2, 1>(a, s);
+  else if (d->KH == 1 && d->KW == 1 && d->pad == 0) rc = (d->Cout <= 64) ? launch<4, 1, 2>(a, s) : launch<2, 2, 2>(a, s);
   else rc = (d->Cout <= 64) ? launch<4, 1, 0>(a, s) : launch<2, 2, 0>(a, s);
   if (rc) return rc;
   const long long total = M * (d->Cout / 4);
