@@ -85,6 +85,29 @@ def test_conv_igemm_vs_torch(case):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
 
 
+def _random_conv_cases(n, seed):
+    import random
+    rnd = random.Random(seed)
+    cases = []
+    while len(cases) < n:
+        k = rnd.choice([1, 1, 3, 3, 5, 7])
+        stride = rnd.choice([1, 1, 2, 3])
+        pad = rnd.choice([0, k // 2, k // 2, 1])
+        Cin = 16 * rnd.randint(1, 6)
+        Cout = rnd.choice([4, 12, 20, 64, 68, 100, 128, 132, 200])
+        H, W = rnd.randint(k, 23), rnd.randint(k, 23)
+        if (H + 2 * pad - k) < 0 or (W + 2 * pad - k) < 0:
+            continue
+        cases.append((rnd.randint(1, 5), Cin, H, W, Cout, k, stride, pad, rnd.random() < 0.5, rnd.random() < 0.4))
+    return cases
+
+
+@pytest.mark.parametrize("case", _random_conv_cases(24, 1234))
+def test_conv_igemm_random_shapes(case):
+    """Ragged everything: odd maps, strides 1-3, any padding, Cout not a multiple of the 64/128 tile."""
+    test_conv_igemm_vs_torch(case)
+
+
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] * c[2] * c[3] <= 3000])
 def test_conv_igemm_latency_mode_split_k(case):
     """Caller-chosen split-K on convolutions (small-batch serving mode): same result as the unsplit
