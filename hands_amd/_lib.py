@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhands_hip.so")
+LIB_PATH = os.environ.get("HANDS_HIP_LIB") or os.path.join(_HERE, "libhands_hip.so")   # HANDS_HIP_LIB: developer A/B builds only
 
 c_float_p = C.c_void_p  # raw device pointers travel as integers
 

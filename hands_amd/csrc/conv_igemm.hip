@@ -155,10 +155,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
         dual_src = a.in2 - a.K0;                                                                    \
         _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) x_base[i] = x_base2[i];                  \
       }                                                                                             \
-      _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) {                                          \
-        xr[i] = x_ok[i] ? *reinterpret_cast<const float4*>(dual_src + (x_base[i] + (KT) * BK + chunk * 4)) \
-                        : make_float4(0.f, 0.f, 0.f, 0.f);                                          \
-      }                                                                                             \
+      /* rows past M were given the address of row 0 above: load unconditionally (their outputs */ \
+      /* are never stored), which keeps the k-loop free of branches                              */ \
+      _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i)                                            \
+        xr[i] = *reinterpret_cast<const float4*>(dual_src + (x_base[i] + (KT) * BK + chunk * 4));   \
     } else {                                                                                        \
       const int toff = (kh * a.W + kw) * a.in_ps + c0 + chunk * 4;                                  \
       _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) {                                          \
