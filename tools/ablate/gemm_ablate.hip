@@ -156,6 +156,62 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const float* __restrict__ 
     *(float4*)(D + (size_t)m * N + n) = make_float4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
   }
 }
+
+// VARIANT 10: 256x128 block tile, 8 waves (512 threads), 3 staging loads per thread per k-step
+__global__ void __launch_bounds__(512, 2) gemm_kernel_big(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ D,
+                                                          int M, int N, int K) {
+  constexpr int BM = 256, BN = 128, BK = 16, LR = 20;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LR];
+  float* sX = lds; float* sW = lds + 2 * BM * LR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int nbn = N / BN;
+  const int m0 = (blockIdx.x / nbn) * BM, n0 = (blockIdx.x % nbn) * BN;
+  const int srow = tid >> 2, chunk = tid & 3;
+  const float* xp0 = X + (size_t)(m0 + srow) * K + chunk * 4; const float* xp1 = xp0 + (size_t)128 * K;
+  const float* wp0 = W + (size_t)(n0 + srow) * K + chunk * 4;
+  float4 xr0, xr1, wr0;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = K / BK;
+#define LOADB(kt) { xr0 = *(const float4*)(xp0 + (kt) * BK); xr1 = *(const float4*)(xp1 + (kt) * BK); wr0 = *(const float4*)(wp0 + (kt) * BK); }
+#define STOREB(buf) { float* dx = sX + (buf) * BM * LR + srow * LR + chunk * 4; float* dw = sW + (buf) * BN * LR + srow * LR + chunk * 4; \
+    *(float4*)dx = xr0; *(float4*)(dx + 128 * LR) = xr1; *(float4*)dw = wr0; }
+  LOADB(0); STOREB(0); __syncthreads();
+  const int frag = (lane & 31) * LR + (lane >> 5) * 4;
+  const float* fw = sW + wn * 64 * LR + frag; const float* fx = sX + wm * 64 * LR + frag;
+  float4 wf[2][2], xf[2][2];
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    const int buf = kt & 1;
+    LOADB(kt + 1);
+    for (int kk = 0; kk < 2; ++kk) for (int i = 0; i < 2; ++i) {
+      wf[i][kk] = *(const float4*)(fw + buf * BN * LR + i * 32 * LR + kk * 8);
+      xf[i][kk] = *(const float4*)(fx + buf * BM * LR + i * 32 * LR + kk * 8); }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(wf[i][kk], t), f4e(xf[j][kk], t), acc[i][j], 0, 0, 0);
+    STOREB(buf ^ 1);
+    __syncthreads();
+  }
+  const int half = lane >> 5;
+  for (int j = 0; j < 2; ++j) for (int i = 0; i < 2; ++i) for (int q = 0; q < 4; ++q) {
+    const int m = m0 + wm * 64 + j * 32 + (lane & 31), n = n0 + wn * 64 + i * 32 + q * 8 + half * 4;
+    *(float4*)(D + (size_t)m * N + n) = make_float4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+  }
+}
+void run_big(const float* X, const float* W, float* D, int M, int N, int K) {
+  dim3 g((M / 256) * (N / 128));
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(gemm_kernel_big, g, dim3(512), 0, 0, X, W, D, M, N, K);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  hipEventRecord(a); const int R = 20;
+  for (int i = 0; i < R; ++i) hipLaunchKernelGGL(gemm_kernel_big, g, dim3(512), 0, 0, X, W, D, M, N, K);
+  hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); ms /= R;
+  printf("%-34s %8.1f us  %6.1f TF/s\n", "10 tile 256x128, 8 waves", ms * 1e3, 2.0 * M * N * K / ms / 1e9);
+}
 template <int V> void run(const float* X, const float* W, float* D, int M, int N, int K, const char* name) {
   dim3 g((M / 128) * (N / 128));
   for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(gemm_kernel<V>, g, dim3(256), 0, 0, X, W, D, M, N, K);
@@ -179,6 +235,7 @@ int main(int argc, char** argv) {
     run<2>(X, W, D, M, N, K, "2 no ds_read (reg operands)");
     run<3>(X, W, D, M, N, K, "3 full, 2 blocks/CU");
     run<4>(X, W, D, M, N, K, "4 MFMA only");
+    run_big(X, W, D, M, N, K);
     run<8>(X, W, D, M, N, K, "8 global loads, no ds_write");
     run<9>(X, W, D, M, N, K, "9 ds_write, no global loads");
     run<6>(X, W, D, M, N, K, "6 global_load_lds direct");
