@@ -41,6 +41,12 @@ def _conv_fns(L, stream, new):
         Ho = (H + 2 * pc.pad - pc.KH) // pc.stride + 1
         Wo = (W + 2 * pc.pad - pc.KW) // pc.stride + 1
         out = out if out is not None else new(B, Ho, Wo, pc.Cout)
+        if HandOccNet.small_map_splitk and H * W > 1 and Ho * Wo <= 64 and "splitk" not in kw:
+            # 8x8 ... 2x2 maps (layer4, the deep hourglass / encoder levels): a handful of output tiles
+            # walking K = 1152-4608 serially.  The slice count depends on the map size and K only, never
+            # on the batch, so every output bit stays independent of the batch size.
+            S = 4 if Ho * Wo > 16 else 8
+            kw["splitk_n"] = max(1, min(S, pc.Kpad // 128))
         HandsLight._conv(L, pc, x, B, H, W, out, act, stream, res=res, **kw)
         return out, Ho, Wo
 
@@ -74,6 +80,7 @@ class HandOccNet(nn.Module):
         self._packed_dev = None
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_packed())
 
+    small_map_splitk = True   # call-site constant split-K on maps of <= 8x8 pixels (see _conv_fns)
     chunks = 2   # the 2*bz crops run as this many jobs on separate HIP streams (1 = single stream)
 
     def _side_stream(self, dev, i):
