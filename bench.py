@@ -210,7 +210,7 @@ def main():
     # ---- CPU baseline (oracle = torch-CPU port of the reference path) + MPJPE checker ----------
     cpu_baseline = None
     parity = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (bounded sample, host cores)
         from oracle import hands_oracle as O
         cb = 2 if hamer else (8 if handocc else args.cpu_bz)
         ci, cm = hands_amd.synthetic_inputs(cb, seed=0)
