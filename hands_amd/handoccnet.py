@@ -239,10 +239,20 @@ class HandOccNet(nn.Module):
             kpe, _, _ = conv(P["kpe2"], k1, B2, 1, 1, ACT_RELU)
             kpe = kpe.view(B2, CF)
             # -- LeakyReLU ResNet-50 (backbone.py:44-53) ------------------------------------------------
-            a, H, W = conv(P["stem"], x4, B2, S, S, ACT_LEAKY_RELU)
+            H, W = (S - 1) // 2 + 1, (S - 1) // 2 + 1
             Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
             cur = new(B2, Hp, Wp, 64)
-            check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(cur), B2, H, W, 64, stream), "maxpool")
+            if HandsLight.fuse_stem_pool:         # conv + BN + LeakyReLU + max-pool in one kernel (bit-identical)
+                hook = HandsLight.conv_hook
+                if hook is not None:
+                    hook("begin", P["stem"], B2 * H * W, stream, False)
+                check(L.hands_stem_conv_maxpool_nhwc_f32(ptr(x4), ptr(P["stem"].w), ptr(P["stem"].bias), ptr(cur), B2, S, S,
+                                                         ACT_LEAKY_RELU, stream), "hands_stem_conv_maxpool_nhwc_f32")
+                if hook is not None:
+                    hook("end", P["stem"], B2 * H * W, stream, False)
+            else:
+                a, H, W = conv(P["stem"], x4, B2, S, S, ACT_LEAKY_RELU)
+                check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(cur), B2, H, W, 64, stream), "maxpool")
             H, W = Hp, Wp
             stages = []
             for blocks in P["layers"]:

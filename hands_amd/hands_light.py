@@ -376,6 +376,7 @@ class HandsLight(nn.Module):
             hook("end", pc, B * Ho * Wo, stream, res is not None)
         return Ho, Wo
 
+    fuse_stem_pool = True   # stem conv + BN + ReLU + max-pool as one kernel (csrc/stem_pool.hip)
     fuse_downsample = True  # first block of each stage: conv3 + downsample + add + ReLU as one two-source GEMM
 
     @staticmethod
@@ -400,8 +401,20 @@ class HandsLight(nn.Module):
         a = self._buf("trunk_a_" + tag, cap, dev); b = self._buf("trunk_b_" + tag, cap, dev)
         t1 = self._buf("trunk_t1_" + tag, cap, dev); t2 = self._buf("trunk_t2_" + tag, cap, dev)
         ds = self._buf("trunk_ds_" + tag, cap, dev)
-        Ho, Wo = self._conv(L, P["stem"], x4, B, H, W, a, True, stream, x_off=x_off)
-        check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(b), B, Ho, Wo, 64, stream), "maxpool")
+        if HandsLight.fuse_stem_pool:
+            # conv1 + bn1 + relu + maxpool in one kernel: the 112x112x64 map never reaches HBM
+            pc = P["stem"]
+            hook = HandsLight.conv_hook
+            Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            if hook is not None:
+                hook("begin", pc, B * Ho * Wo, stream, False)
+            check(L.hands_stem_conv_maxpool_nhwc_f32(ptr(x4, x_off), ptr(pc.w), ptr(pc.bias), ptr(b), B, H, W, 1, stream),
+                  "hands_stem_conv_maxpool_nhwc_f32")
+            if hook is not None:
+                hook("end", pc, B * Ho * Wo, stream, False)
+        else:
+            Ho, Wo = self._conv(L, P["stem"], x4, B, H, W, a, True, stream, x_off=x_off)
+            check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(b), B, Ho, Wo, 64, stream), "maxpool")
         H, W = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
         cur, nxt = b, a
         nblk = len(P["blocks"])

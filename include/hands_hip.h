@@ -98,6 +98,15 @@ int hands_conv1x1_dual_nhwc_f32(const hands_conv_desc* d, const float* in, const
                                 int W2, int stride2, int in2_pix_stride, const float* w_packed,
                                 const float* bias, float* out, hands_stream_t stream);
 
+/* The ResNet stem as one kernel: conv 7x7 / stride 2 / pad 3 on the RGB0 image (B,H,W,4) with the
+ * folded eval-BatchNorm, activation, and max-pool 3x3 / stride 2 / pad 1 -- conv1, bn1, relu, maxpool of
+ * src/nets/backbone/resnet.py:264-268 (LeakyReLU variant: src/models/handoccnet_light/backbone.py:44-47).
+ * w_packed is the stem's hands_conv2d_nhwc_f32 weight ([128][208], k = (kh, kw, rgb0)), bias [>=64];
+ * out (B, Hp, Wp, 64) with Hc = (H-1)/2+1, Hp = (Hc-1)/2+1.  Bit-identical to hands_conv2d_nhwc_f32
+ * followed by hands_maxpool3x3s2_nhwc_f32; the (B,Hc,Wc,64) map is never written to HBM. */
+int hands_stem_conv_maxpool_nhwc_f32(const float* x4, const float* w_packed, const float* bias, float* out,
+                                     int B, int H, int W, int act, hands_stream_t stream);
+
 /* NCHW (B,3,H,W) image batch -> NHWC with C padded to 4 (4th channel = 0).
  * Replaces the implicit layout of inputs["img"|"r_img"|"l_img"] (model.py:188,238-239). */
 int hands_nchw3_to_nhwc4_f32(const float* in, float* out, int B, int H, int W, hands_stream_t stream);

@@ -170,6 +170,36 @@ def test_stem_conv_bn_fold_vs_torch():
     assert (got - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("shape", [(2, 224, 224), (3, 64, 80), (1, 57, 43), (2, 256, 256)])
+@pytest.mark.parametrize("act", [1, 3])
+def test_fused_stem_maxpool_is_bit_identical(shape, act):
+    """hands_stem_conv_maxpool_nhwc_f32 == stem conv (conv_igemm) followed by the max-pool kernel, bit for
+    bit, for full, ragged and odd image sizes (partial pooled tiles, image borders)."""
+    from hands_amd._lib import check, ptr
+    B, H, W = shape
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(B * H + W + act)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    bias = torch.randn(64, generator=g)
+    pc = pack_conv(w, bias, 2, 3, DEV, cin_pad_to=4)
+    x4 = F.pad(_nhwc(torch.randn(B, 3, H, W, generator=g)), (0, 1)).to(DEV).contiguous()
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+    a = torch.empty(B, Hc, Wc, 64, device=DEV)
+    HandsLight._conv(L, pc, x4, B, H, W, a, act, _stream())
+    ref = torch.empty(B, Hp, Wp, 64, device=DEV)
+    check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(ref), B, Hc, Wc, 64, _stream()), "maxpool")
+    got = torch.full((B, Hp, Wp, 64), float("nan"), device=DEV)
+    check(L.hands_stem_conv_maxpool_nhwc_f32(ptr(x4), ptr(pc.w), ptr(pc.bias), ptr(got), B, H, W, act, _stream()), "fused stem")
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref), (got - ref).abs().max().item()
+    # and against torch (fp64) for good measure
+    t = F.conv2d(F.pad(x4[..., :3].permute(0, 3, 1, 2).double().cpu(), (0, 0)), w.double(), bias.double(), stride=2, padding=3)
+    t = F.relu(t) if act == 1 else F.leaky_relu(t, 0.01)
+    t = F.max_pool2d(t, 3, 2, 1)
+    assert (got.cpu().permute(0, 3, 1, 2).double() - t).abs().max().item() < 2e-5
+
+
 def test_layout_pool_kernels():
     L = _lib.lib()
     g = torch.Generator().manual_seed(5)
