@@ -243,13 +243,8 @@ class HandOccNet(nn.Module):
             Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
             cur = new(B2, Hp, Wp, 64)
             if HandsLight.fuse_stem_pool:         # conv + BN + LeakyReLU + max-pool in one kernel (bit-identical)
-                hook = HandsLight.conv_hook
-                if hook is not None:
-                    hook("begin", P["stem"], B2 * H * W, stream, False)
                 check(L.hands_stem_conv_maxpool_nhwc_f32(ptr(x4), ptr(P["stem"].w), ptr(P["stem"].bias), ptr(cur), B2, S, S,
                                                          ACT_LEAKY_RELU, stream), "hands_stem_conv_maxpool_nhwc_f32")
-                if hook is not None:
-                    hook("end", P["stem"], B2 * H * W, stream, False)
             else:
                 a, H, W = conv(P["stem"], x4, B2, S, S, ACT_LEAKY_RELU)
                 check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(cur), B2, H, W, 64, stream), "maxpool")

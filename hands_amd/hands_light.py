@@ -404,14 +404,9 @@ class HandsLight(nn.Module):
         if HandsLight.fuse_stem_pool:
             # conv1 + bn1 + relu + maxpool in one kernel: the 112x112x64 map never reaches HBM
             pc = P["stem"]
-            hook = HandsLight.conv_hook
             Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-            if hook is not None:
-                hook("begin", pc, B * Ho * Wo, stream, False)
             check(L.hands_stem_conv_maxpool_nhwc_f32(ptr(x4, x_off), ptr(pc.w), ptr(pc.bias), ptr(b), B, H, W, 1, stream),
                   "hands_stem_conv_maxpool_nhwc_f32")
-            if hook is not None:
-                hook("end", pc, B * Ho * Wo, stream, False)
         else:
             Ho, Wo = self._conv(L, P["stem"], x4, B, H, W, a, True, stream, x_off=x_off)
             check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(b), B, Ho, Wo, 64, stream), "maxpool")
