@@ -212,6 +212,56 @@ void run_big(const float* X, const float* W, float* D, int M, int N, int K) {
   hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); ms /= R;
   printf("%-34s %8.1f us  %6.1f TF/s\n", "10 tile 256x128, 8 waves", ms * 1e3, 2.0 * M * N * K / ms / 1e9);
 }
+
+// VARIANT 11: model of a patch-based conv k-loop: X fragments from a resident LDS tile (no staging),
+// W fragments straight from global / L2 in operand order (no LDS), one barrier every 9 k-steps.
+__global__ void __launch_bounds__(256, 2) gemm_kernel_patch(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ D,
+                                                            int M, int N, int K) {
+  constexpr int BM = 128, BN = 128, BK = 16, LR = 20;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BM * LR];
+  float* sX = lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int nbn = N / BN;
+  const int m0 = (blockIdx.x / nbn) * BM, n0 = (blockIdx.x % nbn) * BN;
+  for (int i = tid; i < 2 * BM * LR; i += 256) lds[i] = X[(size_t)m0 * K + i % 4096];
+  __syncthreads();
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = K / BK;
+  const int frag = (lane & 31) * LR + (lane >> 5) * 4;
+  const float* fx = sX + wm * 64 * LR + frag;
+  const float* wg = W + (size_t)(n0 + wn * 64 + (lane & 31)) * K + (lane >> 5) * 4;
+  float4 wf[2][2], xf[2][2];
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    for (int kk = 0; kk < 2; ++kk) for (int i = 0; i < 2; ++i) {
+      wf[i][kk] = *(const float4*)(wg + (size_t)i * 32 * K + kt * BK + kk * 8);
+      xf[i][kk] = *(const float4*)(fx + buf * BM * LR + i * 32 * LR + kk * 8); }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(wf[i][kk], t), f4e(xf[j][kk], t), acc[i][j], 0, 0, 0);
+    if (kt % 9 == 8) __syncthreads();
+  }
+  const int half = lane >> 5;
+  for (int j = 0; j < 2; ++j) for (int i = 0; i < 2; ++i) for (int q = 0; q < 4; ++q) {
+    const int m = m0 + wm * 64 + j * 32 + (lane & 31), n = n0 + wn * 64 + i * 32 + q * 8 + half * 4;
+    *(float4*)(D + (size_t)m * N + n) = make_float4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+  }
+}
+void run_patch(const float* X, const float* W, float* D, int M, int N, int K) {
+  dim3 g((M / 128) * (N / 128));
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(gemm_kernel_patch, g, dim3(256), 0, 0, X, W, D, M, N, K);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  hipEventRecord(a); const int R = 20;
+  for (int i = 0; i < R; ++i) hipLaunchKernelGGL(gemm_kernel_patch, g, dim3(256), 0, 0, X, W, D, M, N, K);
+  hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); ms /= R;
+  printf("%-34s %8.1f us  %6.1f TF/s\n", "11 patch model: X in LDS, W from L2", ms * 1e3, 2.0 * M * N * K / ms / 1e9);
+}
 template <int V> void run(const float* X, const float* W, float* D, int M, int N, int K, const char* name) {
   dim3 g((M / 128) * (N / 128));
   for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(gemm_kernel<V>, g, dim3(256), 0, 0, X, W, D, M, N, K);
@@ -236,6 +286,7 @@ int main(int argc, char** argv) {
     run<3>(X, W, D, M, N, K, "3 full, 2 blocks/CU");
     run<4>(X, W, D, M, N, K, "4 MFMA only");
     run_big(X, W, D, M, N, K);
+    run_patch(X, W, D, M, N, K);
     run<8>(X, W, D, M, N, K, "8 global loads, no ds_write");
     run<9>(X, W, D, M, N, K, "9 ds_write, no global loads");
     run<6>(X, W, D, M, N, K, "6 global_load_lds direct");
