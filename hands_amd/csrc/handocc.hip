@@ -132,15 +132,29 @@ __global__ void add_rowvec_kernel(const float4* __restrict__ x, const float4* __
   }
 }
 
-// out[b,c] = sum_t x[b,t,c]   (the key sum of the FIT gate)
-__global__ void token_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int N, int C) {
-  const int total = B * C;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int b = i / C, c = i - b * C;
-    const float* p = x + (long long)b * N * C + c;
-    float s = 0.f;
-    for (int t = 0; t < N; ++t) s += p[(long long)t * C];
-    out[i] = s;
+// out[b,c] = sum_t x[b,t,c]   (the key sum of the FIT gate).  One workgroup per (sample, 64 channels):
+// 16 token groups x 16 float4 columns; group g adds tokens g, g+16, ... in order, then the 16 partial
+// sums are added in group order -- a fixed order for every batch size.
+__global__ void __launch_bounds__(256) token_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int N, int C) {
+  __shared__ float4 part[16][16];
+  const int cblocks = C / 64;
+  const int b = blockIdx.x / cblocks, cb = blockIdx.x - b * cblocks;
+  const int g = threadIdx.x >> 4, c4 = threadIdx.x & 15;
+  const float4* p = reinterpret_cast<const float4*>(x + ((long long)b * N) * C + cb * 64) + c4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = g; t < N; t += 16) {
+    const float4 v = p[(long long)t * (C / 4)];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  part[g][c4] = s;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float4 a = part[0][threadIdx.x];
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = part[k][threadIdx.x];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + (long long)b * C + cb * 64 + threadIdx.x * 4) = a;
   }
 }
 
@@ -383,8 +397,8 @@ int hands_add_rowvec_f32(const float* x, const float* vec, float* out, int B, in
 }
 
 int hands_token_sum_f32(const float* x, float* out, int B, int N, int C, hands_stream_t stream) {
-  if (!x || !out || B <= 0 || N <= 0) return HANDS_EINVAL;
-  hipLaunchKernelGGL(token_sum_kernel, dim3(hands_grid_1d((long long)B * C, 64)), dim3(64), 0, S(stream), x, out, B, N, C);
+  if (!x || !out || B <= 0 || N <= 0 || C <= 0 || C % 64) return HANDS_EINVAL;
+  hipLaunchKernelGGL(token_sum_kernel, dim3((unsigned)(B * (C / 64))), dim3(256), 0, S(stream), x, out, B, N, C);
   HANDS_LAUNCH_CHECK();
 }
 
