@@ -261,6 +261,15 @@ class HAMER(nn.Module):
             self._packed_dev = dev
         return self._packed
 
+    chunks = 2   # the 2*bz crops run as this many jobs on separate HIP streams (1 = single stream)
+
+    def _side_stream(self, dev, i):
+        key = ("side_stream", i)
+        st = self._ws.get(key)
+        if st is None or st.device != dev:
+            st = self._ws[key] = torch.cuda.Stream(device=dev)
+        return st
+
     def _buf(self, name, numel, dev):
         t = self._ws.get(name)
         if t is None or t.numel() < numel or t.device != dev:
@@ -304,44 +313,81 @@ class HAMER(nn.Module):
         check(L.hands_kpe_encode_f32(ptr(center), ptr(corner), ptr(enc), B2, kld, self.n_freq, stream), "kpe_encode")
         hgemm(P["kpe0"], enc, B2, k1, ACT_RELU)
         hgemm(P["kpe2"], k1, B2, kpe, ACT_RELU)
-        # -- ViT-H/16 (vit.py:320-342) ---------------------------------------------------------------
-        x = buf("vit_x", M * Cd)
-        ho, wo = HandsLight._conv(L, P["patch"], x4, B2, S, Wc, x, ACT_NONE, stream)
-        assert (ho, wo) == (TOKENS_H, TOKENS_W)
-        check(L.hands_add_pos_f32(ptr(x), ptr(P["pos"]), ptr(kpe), B2, T, Cd, stream), "add_pos")
-        y, qkv, att, hid = buf("vit_y", M * Cd), buf("vit_qkv", M * 3 * Cd), buf("vit_att", M * Cd), buf("vit_h", M * 4 * Cd)
-        scale = float(VIT_HDIM ** -0.5)
-        for blk in P["blocks"]:
-            lnorm(x, blk["n1"], y, M, Cd, 1e-6)
-            gemm(blk["qkv"], y, M, qkv)
-            check(L.hands_attention_f32(ptr(qkv), ptr(att), B2, T, VIT_HEADS, VIT_HDIM, scale, stream), "attention")
-            gemm(blk["proj"], att, M, x, res=x)
-            lnorm(x, blk["n2"], y, M, Cd, 1e-6)
-            gemm(blk["fc1"], y, M, hid, ACT_GELU)
-            gemm(blk["fc2"], hid, M, x, res=x)
-        feat = buf("vit_feat", M * Cd)
-        lnorm(x, P["last"], feat, M, Cd, 1e-6, addvec=kpe, rpv=T)       # last_norm, + kpe (model.py:102-104)
-        # -- decoder head (mano_head.py:58-112) -----------------------------------------------------
-        inner = DEC_HEADS * DEC_HDIM
-        xd = P["tok0"].expand(B2, DEC_DIM).contiguous()
-        yd, v512, q512, o512 = buf("dec_y", B2 * DEC_DIM), buf("dec_v", B2 * inner), buf("dec_q", B2 * inner), buf("dec_o", B2 * inner)
-        kv, hd = buf("dec_kv", M * 2 * inner), buf("dec_h", B2 * DEC_DIM)
-        dscale = float(DEC_HDIM ** -0.5)
-        for lay in P["dec"]:
-            lnorm(xd, lay["n0"], yd, B2, DEC_DIM, 1e-5)
-            hgemm(lay["v"], yd, B2, v512)
-            hgemm(lay["o0"], v512, B2, xd, res=xd)
-            lnorm(xd, lay["n1"], yd, B2, DEC_DIM, 1e-5)
-            hgemm(lay["q"], yd, B2, q512)
-            gemm(lay["kv"], feat, M, kv)
-            check(L.hands_cross_attention_1q_f32(ptr(q512), ptr(kv), ptr(o512), B2, T, DEC_HEADS, DEC_HDIM, dscale,
-                                                 stream), "cross_attention")
-            hgemm(lay["o1"], o512, B2, xd, res=xd)
-            lnorm(xd, lay["n2"], yd, B2, DEC_DIM, 1e-5)
-            hgemm(lay["f0"], yd, B2, hd, ACT_GELU)
-            hgemm(lay["f3"], hd, B2, xd, res=xd)
+        # -- ViT-H/16 + decoder head, per chunk of crops -----------------------------------------------
         pred = torch.empty(B2, 112, device=dev)
-        hgemm(P["decout"], xd, B2, pred, res=P["init"], res_ps=0)          # dec*(token) + mean params
+        inner = DEC_HEADS * DEC_HDIM
+        scale = float(VIT_HDIM ** -0.5)
+        dscale = float(DEC_HDIM ** -0.5)
+
+        def pipeline(lo, nB, st, tag):
+            """Crops [lo, lo+nB): everything from the patch embedding to the 112-vector of the decoder.
+            Rows are independent, so chunks of crops run on separate HIP streams: the attention /
+            layer-norm launches of one chunk overlap the GEMMs of the other."""
+            sh = st.cuda_stream
+            Mc = nB * T
+            cbuf = lambda n, numel: self._buf(f"{n}@{tag}", numel, dev)
+            gemm = lambda pc, x, rows, out, act=ACT_NONE, **kw: HandsLight._conv(L, pc, x, rows, 1, 1, out, act, sh, **kw)
+            hgemm = lambda *a, **kw: gemm(*a, splitk=True, **kw)
+            lnorm = lambda x, gb, out, rows, Cc, eps, addvec=None, rpv=1: check(
+                L.hands_layernorm_f32(ptr(x), ptr(gb[0]), ptr(gb[1]), ptr(out), addvec, rpv, rows, Cc, eps, sh), "layernorm")
+            # ViT-H/16 (vit.py:320-342)
+            x = cbuf("vit_x", Mc * Cd)
+            ho, wo = HandsLight._conv(L, P["patch"], x4, nB, S, Wc, x, ACT_NONE, sh, x_off=lo * S * Wc * 4)
+            assert (ho, wo) == (TOKENS_H, TOKENS_W)
+            check(L.hands_add_pos_f32(ptr(x), ptr(P["pos"]), ptr(kpe, lo * Cd), nB, T, Cd, sh), "add_pos")
+            y, qkv, att, hid = cbuf("vit_y", Mc * Cd), cbuf("vit_qkv", Mc * 3 * Cd), cbuf("vit_att", Mc * Cd), cbuf("vit_h", Mc * 4 * Cd)
+            for blk in P["blocks"]:
+                lnorm(x, blk["n1"], y, Mc, Cd, 1e-6)
+                gemm(blk["qkv"], y, Mc, qkv)
+                check(L.hands_attention_f32(ptr(qkv), ptr(att), nB, T, VIT_HEADS, VIT_HDIM, scale, sh), "attention")
+                gemm(blk["proj"], att, Mc, x, res=x)
+                lnorm(x, blk["n2"], y, Mc, Cd, 1e-6)
+                gemm(blk["fc1"], y, Mc, hid, ACT_GELU)
+                gemm(blk["fc2"], hid, Mc, x, res=x)
+            feat = cbuf("vit_feat", Mc * Cd)
+            lnorm(x, P["last"], feat, Mc, Cd, 1e-6, addvec=ptr(kpe, lo * Cd), rpv=T)   # last_norm, + kpe (model.py:102-104)
+            # decoder head (mano_head.py:58-112)
+            xd = cbuf("dec_x", nB * DEC_DIM)
+            xd[: nB * DEC_DIM].view(nB, DEC_DIM).copy_(P["tok0"].expand(nB, DEC_DIM))
+            yd, v512, q512, o512 = cbuf("dec_y", nB * DEC_DIM), cbuf("dec_v", nB * inner), cbuf("dec_q", nB * inner), cbuf("dec_o", nB * inner)
+            kv, hd = cbuf("dec_kv", Mc * 2 * inner), cbuf("dec_h", nB * DEC_DIM)
+            for lay in P["dec"]:
+                lnorm(xd, lay["n0"], yd, nB, DEC_DIM, 1e-5)
+                hgemm(lay["v"], yd, nB, v512)
+                hgemm(lay["o0"], v512, nB, xd, res=xd)
+                lnorm(xd, lay["n1"], yd, nB, DEC_DIM, 1e-5)
+                hgemm(lay["q"], yd, nB, q512)
+                gemm(lay["kv"], feat, Mc, kv)
+                check(L.hands_cross_attention_1q_f32(ptr(q512), ptr(kv), ptr(o512), nB, T, DEC_HEADS, DEC_HDIM, dscale, sh),
+                      "cross_attention")
+                hgemm(lay["o1"], o512, nB, xd, res=xd)
+                lnorm(xd, lay["n2"], yd, nB, DEC_DIM, 1e-5)
+                hgemm(lay["f0"], yd, nB, hd, ACT_GELU)
+                hgemm(lay["f3"], hd, nB, xd, res=xd)
+            hgemm(P["decout"], xd, nB, pred, res=P["init"], res_ps=0, out_off=lo * 112)   # dec*(token) + mean params
+
+        main = torch.cuda.current_stream(dev)
+        nch = HAMER.chunks if HandsLight.overlap_trunks else 1
+        nch = max(1, min(nch, B2))
+        if nch == 1:
+            pipeline(0, B2, main, "c0")
+        else:
+            ev0 = torch.cuda.Event()
+            ev0.record(main)
+            done = []
+            for ci in range(nch):
+                lo, hi = ci * B2 // nch, (ci + 1) * B2 // nch
+                st = main if ci == nch - 1 else self._side_stream(dev, ci)
+                if st is not main:
+                    st.wait_event(ev0)
+                with torch.cuda.stream(st):
+                    pipeline(lo, hi - lo, st, f"c{ci}")
+                if st is not main:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    done.append(ev)
+            for ev in done:
+                main.wait_event(ev)
         rot = torch.empty(B2, 16, 3, 3, device=dev)
         check(L.hands_rot6d_to_matrix_cols_f32(ptr(pred), 112, ptr(rot), B2, stream), "rot6d_cols")
         shape = pred[:, 96:106].contiguous()
