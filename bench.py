@@ -249,7 +249,7 @@ def main():
         parity = {"mpjpe_vs_ref_mm": round(mp, 7), "max_vertex_err_m": float(f"{verr:.3e}"), "checked_hands": 2 * cb}
 
     line = {
-        "metric": "hands_per_sec", "value": round(hands_per_s, 1), "unit": "hands/s", "n_gpus": n_gpus,
+        "metric": "hands/sec", "value": round(hands_per_s, 1), "unit": "hands/s", "n_gpus": n_gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",

@@ -126,7 +126,7 @@ def main():
                    (out["mano.vertices.l"][:cb].cpu() - ref[1]["vertices.l"]).abs().max().item())
         parity = {"max_vertex_err_m": float(f"{verr:.3e}"), "checked_hands": 2 * cb}
     print(json.dumps({
-        "metric": "hands_per_sec", "value": round(hands, 1), "unit": "hands/s", "n_gpus": world, "steps": args.steps,
+        "metric": "hands/sec", "value": round(hands, 1), "unit": "hands/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "strong" if not args.bz else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"two-hand MANO LBS (MANOHead.forward x2), {bz} crops/GPU, {world} GPU(s)"
