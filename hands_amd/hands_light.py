@@ -305,6 +305,17 @@ class HandsLight(nn.Module):
             m["consts"] = mano_consts(m)
         return P
 
+    def replica(self):
+        """A second handle on the SAME parameters and packed weights with its own workspaces and side
+        streams, for a second request stream: two forwards in flight (one per torch stream, one replica
+        each) overlap the 3 ms tail of one with the trunks of the other (+2 % throughput measured).
+        Plain PyTorch stream semantics: each forward's outputs are valid on the stream it was called on."""
+        self.packed(next(self.parameters()).device)
+        import copy
+        r = copy.copy(self)
+        r._ws = {}
+        return r
+
     def packed(self, dev):
         if self._packed is None or self._packed_dev != dev:
             self._packed = self._pack(dev)

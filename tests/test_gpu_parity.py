@@ -428,6 +428,26 @@ def test_graphed_forward_is_bit_identical(gpu_model):
         gf(bad, meta3)
 
 
+def test_replica_on_a_second_stream(gpu_model):
+    """Two forwards in flight on two streams (model + replica sharing the packed weights): same bits as
+    the plain call."""
+    inputs, meta_info = synthetic_inputs(4, 3, device=DEV)
+    ref = {k: v.clone() for k, v in gpu_model(inputs, meta_info).items()}
+    rep = gpu_model.replica()
+    assert rep._packed is gpu_model._packed and rep._ws is not gpu_model._ws
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for i in range(4):
+        m, st = (gpu_model, s0) if i % 2 == 0 else (rep, s1)
+        with torch.cuda.stream(st):
+            outs.append(m(inputs, meta_info))
+    torch.cuda.synchronize()
+    for o in outs:
+        for k in ref:
+            assert torch.equal(o[k], ref[k]), k
+
+
 def test_forward_vs_oracle_with_flips(recipe_sd, gpu_model):
     inputs, meta_info = synthetic_inputs(3, 5)
     meta_info["is_flipped"] = torch.tensor([1, 0, 1])
