@@ -47,6 +47,9 @@ def _conv_fns(L, stream, new):
             # on the batch, so every output bit stays independent of the batch size.
             S = 4 if Ho * Wo > 16 else 8
             kw["splitk_n"] = max(1, min(S, pc.Kpad // 128))
+        elif (HandOccNet.small_map_splitk and H * W > 1 and Ho * Wo <= 256 and pc.Cout <= 128 and pc.Kpad >= 1024
+              and "splitk" not in kw):
+            kw["splitk_n"] = 2          # 16x16 maps, one n-tile: 2 output tiles per crop
         HandsLight._conv(L, pc, x, B, H, W, out, act, stream, res=res, **kw)
         return out, Ho, Wo
 
