@@ -23,6 +23,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HANDS_SYNTHETIC_MANO", "1")   # synthetic MANO asset (data: "synthetic"); the licensed files are not here
 
 import torch
 import torch.distributed as dist

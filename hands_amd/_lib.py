@@ -60,6 +60,8 @@ SIGNATURES = {
     "hands_hmr_init_f32": [_P, _P, _I, _I, _I, _P],
     "hands_rot6d_to_matrix_f32": [_P, _I, _P, _I, _P],
     "hands_flip_swap_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "hands_matrix_to_axis_angle_f32": [_P, _P, C.c_longlong, _P],
+    "hands_axis_angle_to_matrix_f32": [_P, _P, C.c_longlong, _P],
     "hands_grasp_input_f32": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "hands_mano_pose_f32": [C.POINTER(ManoConsts), _P, _P, _I, _P, _I, _P, _P, _I, _P],
     "hands_mano_skin_f32": [C.POINTER(ManoConsts), _P, _I, _P, _P, _P, _P, _F, _F, C.POINTER(ManoOut), _I, _P],

@@ -344,6 +344,29 @@ int splitk_factor(const hands_conv_desc* d) {
   return s > 8 ? 8 : s;
 }
 
+// geometry checks shared by the entry points: offsets are 32-bit inside the kernel and the output map must be
+// the one the (H, W, K, stride, pad) geometry produces, or the k-loop would read outside the input
+bool conv_geometry_ok(const hands_conv_desc* d) {
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 ||
+      d->pad < 0)
+    return false;
+  if (d->Cin % 4 || d->Cout % 4 || d->Kpad % BK || d->Kpad < d->KH * d->KW * d->Cin) return false;
+  if (d->Cin != 4 && d->Cin % 16) return false;
+  if (d->in_pix_stride < d->Cin || d->out_pix_stride < d->Cout) return false;
+  // last output pixel's window must start inside the padded input
+  if ((long long)(d->Ho - 1) * d->stride - d->pad >= d->H || (long long)(d->Wo - 1) * d->stride - d->pad >= d->W) return false;
+  if ((long long)d->B * d->H * d->W * d->in_pix_stride >= (1LL << 31)) return false;
+  if ((long long)d->B * d->Ho * d->Wo >= (1LL << 31) / (d->out_pix_stride > 0 ? d->out_pix_stride : 1)) return false;
+  return true;
+}
+
+// the branch-free pointwise k-loop (MODE 2 with its source switch out of reach) has no bounds checks: it
+// needs every tap inside the image and the weight row to be exactly the pixel's channels
+bool pointwise_route_ok(const hands_conv_desc* d) {
+  return d->KH == 1 && d->KW == 1 && d->pad == 0 && d->Cin != 4 && d->Kpad == d->Cin &&
+         (long long)(d->Ho - 1) * d->stride < d->H && (long long)(d->Wo - 1) * d->stride < d->W;
+}
+
 }  // namespace
 
 extern "C" int hands_conv2d_splitk_factor(const hands_conv_desc* d) { return d ? splitk_factor(d) : 0; }
@@ -352,14 +375,8 @@ extern "C" int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, 
                                      const float* bias, const float* residual, float* out,
                                      hands_stream_t stream) {
   if (!d || !in || !w_packed || !bias || !out) return HANDS_EINVAL;
-  if (d->B <= 0 || d->Cin % 4 || d->Cout % 4 || d->Kpad % BK || d->Kpad < d->KH * d->KW * d->Cin)
-    return HANDS_EINVAL;
+  if (!conv_geometry_ok(d)) return HANDS_EINVAL;
   const bool stem = d->Cin == 4;
-  if (!stem && d->Cin % 16) return HANDS_EINVAL;
-  if (d->in_pix_stride < d->Cin || d->out_pix_stride < d->Cout) return HANDS_EINVAL;
-  // offsets are kept in 32-bit float units inside the kernel
-  const long long in_elems = (long long)d->B * d->H * d->W * d->in_pix_stride;
-  if (in_elems >= (1LL << 31)) return HANDS_EINVAL;
   ConvArgs a;
   a.in = in; a.w = w_packed; a.bias = bias; a.res = residual; a.out = out;
   a.M = d->B * d->Ho * d->Wo; a.N = d->Cout; a.Kpad = d->Kpad;
@@ -373,7 +390,7 @@ extern "C" int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, 
   if (stem) return (d->Cout <= 64) ? launch<4, 1, 1>(a, s) : launch<2, 2, 1>(a, s);
   // pointwise layers (1x1, no padding; any stride) take the two-source instantiation with the switch
   // point out of reach: no tap state and no bounds checks in the k-loop
-  if (d->KH == 1 && d->KW == 1 && d->pad == 0) return (d->Cout <= 64) ? launch<4, 1, 2>(a, s) : launch<2, 2, 2>(a, s);
+  if (pointwise_route_ok(d)) return (d->Cout <= 64) ? launch<4, 1, 2>(a, s) : launch<2, 2, 2>(a, s);
   return (d->Cout <= 64) ? launch<4, 1, 0>(a, s) : launch<2, 2, 0>(a, s);
 }
 
@@ -411,12 +428,8 @@ extern "C" int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const fl
   if (S > d->Kpad / BK) S = d->Kpad / BK;
   if (S <= 1 || !workspace || workspace_floats < (long long)S * M * part_ps)
     return hands_conv2d_nhwc_f32(d, in, w_packed, bias, residual, out, stream);
-  if (!in || !w_packed || !bias || !out || d->B <= 0 || d->Cout % 4 || d->Kpad % BK || d->Kpad < d->KH * d->KW * d->Cin ||
-      d->in_pix_stride < d->Cin || d->out_pix_stride < d->Cout || S > 64)
-    return HANDS_EINVAL;
+  if (!in || !w_packed || !bias || !out || !conv_geometry_ok(d) || S > 64) return HANDS_EINVAL;
   const bool stem = d->Cin == 4;
-  if (!stem && d->Cin % 16) return HANDS_EINVAL;
-  if ((long long)d->B * d->H * d->W * d->in_pix_stride >= (1LL << 31) || M >= (1LL << 31)) return HANDS_EINVAL;
   ConvArgs a;
   a.in = in; a.w = w_packed; a.bias = bias; a.res = nullptr; a.out = out;
   a.M = (int)M; a.N = d->Cout; a.Kpad = d->Kpad;
@@ -429,7 +442,7 @@ extern "C" int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const fl
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (stem) rc = (d->Cout <= 64) ? launch<4, 1, 1>(a, s) : launch<2, 2, 1>(a, s);
-  else if (d->KH == 1 && d->KW == 1 && d->pad == 0) rc = (d->Cout <= 64) ? launch<4, 1, 2>(a, s) : launch<2, 2, 2>(a, s);
+  else if (pointwise_route_ok(d)) rc = (d->Cout <= 64) ? launch<4, 1, 2>(a, s) : launch<2, 2, 2>(a, s);
   else rc = (d->Cout <= 64) ? launch<4, 1, 0>(a, s) : launch<2, 2, 0>(a, s);
   if (rc) return rc;
   const long long total = M * (d->Cout / 4);

@@ -190,6 +190,24 @@ __global__ void grasp_input_kernel(const float* __restrict__ shape, int ld_shape
   }
 }
 
+// ---- rotation conversions alone (the device functions mano_pose_kernel / flip_swap_kernel use) -------
+__global__ void matrix_to_axis_angle_kernel(const float* __restrict__ rotmat, float* __restrict__ aa, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float v[3];
+    hands::matrix_to_axis_angle(rotmat + i * 9, v);
+    aa[i * 3 + 0] = v[0]; aa[i * 3 + 1] = v[1]; aa[i * 3 + 2] = v[2];
+  }
+}
+
+__global__ void axis_angle_to_matrix_kernel(const float* __restrict__ aa, float* __restrict__ rotmat, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float m[9];
+    hands::axis_angle_to_matrix(aa + i * 3, m);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) rotmat[i * 9 + e] = m[e];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -265,6 +283,20 @@ int hands_grasp_input_f32(const float* shape, int ld_shape, const float* rotmat,
     return HANDS_EINVAL;
   hipLaunchKernelGGL(grasp_input_kernel, dim3(hands_grid_1d((long long)B2 * ld_out, 256)), dim3(256), 0,
                      (hipStream_t)stream, shape, ld_shape, rotmat, feat_vec, out, B2, Bg, F, ld_out);
+  HANDS_LAUNCH_CHECK();
+}
+
+int hands_matrix_to_axis_angle_f32(const float* rotmat, float* axis_angle, long long n, hands_stream_t stream) {
+  if (!rotmat || !axis_angle || n <= 0) return HANDS_EINVAL;
+  hipLaunchKernelGGL(matrix_to_axis_angle_kernel, dim3(hands_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     rotmat, axis_angle, n);
+  HANDS_LAUNCH_CHECK();
+}
+
+int hands_axis_angle_to_matrix_f32(const float* axis_angle, float* rotmat, long long n, hands_stream_t stream) {
+  if (!rotmat || !axis_angle || n <= 0) return HANDS_EINVAL;
+  hipLaunchKernelGGL(axis_angle_to_matrix_kernel, dim3(hands_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     axis_angle, rotmat, n);
   HANDS_LAUNCH_CHECK();
 }
 

@@ -158,14 +158,19 @@ class _KPE(nn.Module):
                                       nn.Linear(VIT_DIM, VIT_DIM), nn.ReLU(inplace=True))
 
 
-def load_mano_mean_params():
-    """$DATA_DIR/hamer/_DATA/data/mano_mean_params.npz when present (mano_head.py:49-50), the
-    synthetic stand-in otherwise."""
+def load_mano_mean_params(allow_synthetic=None):
+    """$DATA_DIR/hamer/_DATA/data/mano_mean_params.npz (mano_head.py:49-50).  The reference fails when
+    the file is missing; so does this unless the synthetic stand-in was asked for explicitly
+    (argument or HANDS_SYNTHETIC_MANO=1, see hands_amd.mano.synthetic_allowed)."""
+    from .mano import synthetic_allowed
     fn = os.path.join(os.environ.get("DATA_DIR", ""), "hamer", "_DATA", "data", "mano_mean_params.npz")
     if os.path.isfile(fn):
         d = np.load(fn)
         return {k: d[k] for k in ("pose", "shape", "cam")}
-    return synthetic_mano_mean_params()
+    if synthetic_allowed(allow_synthetic):
+        return synthetic_mano_mean_params()
+    raise FileNotFoundError(f"hands_amd: {fn!r} not found; set $DATA_DIR, pass mean_params=..., or opt in to the "
+                            "synthetic mean parameters with HANDS_SYNTHETIC_MANO=1 (tests / benchmarks only)")
 
 
 HAMER_DEFAULT_ARGS = _Args(pos_enc="center+corner_latent", n_freq_pos_enc=4, use_grasp_loss=True,

@@ -135,13 +135,38 @@ def load_mano_pkl(path: str, is_rhand: bool) -> ManoAsset:
                      is_rhand).validate()
 
 
-def build_mano_asset(is_rhand: bool) -> ManoAsset:
-    """Real asset from ``$MANO_DIR`` when present, the synthetic one otherwise (said loudly)."""
+def synthetic_allowed(allow_synthetic=None) -> bool:
+    """The synthetic stand-ins (MANO asset, hamer mean parameters) are an explicit opt-in: an argument,
+    or HANDS_SYNTHETIC_MANO=1 (set by tests/conftest.py, bench.py, smoke() and the tools)."""
+    if allow_synthetic is not None:
+        return bool(allow_synthetic)
+    return os.environ.get("HANDS_SYNTHETIC_MANO", "") == "1"
+
+
+def build_mano_asset(is_rhand: bool, allow_synthetic=None) -> ManoAsset:
+    """The real asset from ``$MANO_DIR/MANO_{RIGHT,LEFT}.pkl`` (common/body_models.py:90-99).  Without
+    it the reference hard-fails (``os.environ['MANO_DIR']``); so does this, unless the synthetic
+    stand-in was asked for explicitly -- a model that silently serves a random hand template would
+    produce well-shaped, meaningless meshes."""
     mano_dir = os.environ.get("MANO_DIR", "")
     fn = os.path.join(mano_dir, "MANO_RIGHT.pkl" if is_rhand else "MANO_LEFT.pkl")
     if mano_dir and os.path.isfile(fn):
         return load_mano_pkl(fn, is_rhand)
-    return synthetic_mano_asset(is_rhand)
+    if synthetic_allowed(allow_synthetic):
+        return synthetic_mano_asset(is_rhand)
+    raise FileNotFoundError(
+        f"hands_amd: MANO asset not found ({fn!r}; $MANO_DIR={mano_dir!r}).  Point $MANO_DIR at the licensed "
+        "MANO_RIGHT.pkl / MANO_LEFT.pkl, pass mano_assets=(right, left) ManoAsset objects, or opt in to the "
+        "synthetic stand-in with HANDS_SYNTHETIC_MANO=1 (tests / benchmarks only).")
+
+
+# buffers smplx.MANO(use_pca=False, flat_hand_mean=False) registers (smplx/body_models.py, SMPL.__init__ +
+# MANO.__init__; third party, absent here -> names restated from the published source, "parity unpinned").
+# Its nn.Parameters (betas, global_orient, hand_pose) and the vertex_joint_selector index buffer are not
+# used by the forward path (the reference passes betas / poses explicitly, mano_head.py:34-38) and are
+# reported as unexpected keys by load_state_dict(strict=False), exactly like any other extra key.
+SMPLX_MANO_BUFFERS = ("faces_tensor", "v_template", "shapedirs", "J_regressor", "posedirs", "parents",
+                      "lbs_weights", "hand_mean", "pose_mean")
 
 
 class ManoLayer(nn.Module):
@@ -157,6 +182,7 @@ class ManoLayer(nn.Module):
         self.register_buffer("posedirs", torch.from_numpy(asset.posedirs.copy()))
         self.register_buffer("parents", torch.tensor(PARENTS, dtype=torch.long))
         self.register_buffer("lbs_weights", torch.from_numpy(asset.lbs_weights.copy()))
+        self.register_buffer("hand_mean", torch.from_numpy(asset.hands_mean.copy()))
         pose_mean = np.concatenate([np.zeros(3, np.float32), asset.hands_mean])
         self.register_buffer("pose_mean", torch.from_numpy(pose_mean))
 

@@ -148,6 +148,14 @@ int hands_flip_swap_f32(const int64_t* is_flipped, const float* rotmat, const fl
                         float* shape_out, float* cam_out, float* cam_init_out, int Bg,
                         hands_stream_t stream);
 
+/* The rotation conversions of the MANO head on their own (the same device functions
+ * hands_mano_pose_f32 and hands_flip_swap_f32 inline): matrix_to_axis_angle =
+ * quaternion_to_axis_angle(matrix_to_quaternion(.)) (common/rot.py:118-193, 55-83; called at
+ * src/nets/hand_heads/mano_head.py:27-31) and its inverse axis_angle_to_matrix (common/rot.py:754-782,
+ * 86-115; model.py:345-353).  rotmat (n,3,3) row-major, axis_angle (n,3). */
+int hands_matrix_to_axis_angle_f32(const float* rotmat, float* axis_angle, long long n, hands_stream_t stream);
+int hands_axis_angle_to_matrix_f32(const float* axis_angle, float* rotmat, long long n, hands_stream_t stream);
+
 /* grasp-head input rows [feat_vec(F) | rotmat(144) | shape(10) | 0-pad]: the reference's
  * cat([shape, pose.view(bz,-1), feat_vec]) (model.py:401-404) with the columns permuted so the
  * segments are 16-byte aligned; the packed grasp_classifier.0 weight uses the same permutation.

@@ -7,6 +7,9 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the licensed MANO files / hamer mean parameters are not here: the tests opt in to the synthetic
+# stand-ins (hands_amd.mano.build_mano_asset raises without this, like the reference without $MANO_DIR)
+os.environ.setdefault("HANDS_SYNTHETIC_MANO", "1")
 
 
 def pytest_configure(config):

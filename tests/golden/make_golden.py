@@ -53,10 +53,12 @@ def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
     model = build_reference()
     meta = dict(META)
+    only_bz1 = "--bz1-only" in sys.argv      # add the BASELINE configs[0] fixture without touching the others
 
-    # ---- full forward, bz=2, seeds 0..2; seed 2 has one flipped sample -----------------------
-    for seed in (0, 1, 2):
-        inputs, meta_info = synthetic_inputs(2, seed)
+    # ---- full forward: bz=2, seeds 0..2 (seed 2 has one flipped sample); bz=1, seed 0 = BASELINE
+    #      configs[0] "single 224x224 crop, bs=1"  -----------------------------
+    for bz, seed in ((1, 0),) if only_bz1 else ((2, 0), (2, 1), (2, 2), (1, 0)):
+        inputs, meta_info = synthetic_inputs(bz, seed)
         if seed == 2:
             meta_info["is_flipped"] = torch.tensor([0, 1])
         cap = {}
@@ -89,10 +91,12 @@ def main():
             rec[f"hmr_{hn}/pose_6d"] = h["pose_6d"].numpy()
             rec[f"hmr_{hn}/shape"] = h["shape"].numpy()
             rec[f"hmr_{hn}/cam_t.wp"] = h["cam_t.wp"].numpy()
-        rec["meta"] = np.array(json.dumps(dict(meta, seed=seed, bz=2)))
-        np.savez_compressed(os.path.join(out_dir, f"hands_light_bz2_seed{seed}.npz"), **rec)
+        rec["meta"] = np.array(json.dumps(dict(meta, seed=seed, bz=bz)))
+        np.savez_compressed(os.path.join(out_dir, f"hands_light_bz{bz}_seed{seed}.npz"), **rec)
         print("seed", seed, "ok;  |verts.r| max", float(out["mano.vertices.r"].abs().max()),
               " beta.r", out["mano.beta.r"][0, :3].tolist(), " cam", out["mano.cam_t.wp.r"][0].tolist())
+    if only_bz1:
+        return
 
     # ---- rotation conversions: reference common/rot.py on random + adversarial rotations ----
     g = torch.Generator().manual_seed(7)

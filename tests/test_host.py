@@ -137,6 +137,14 @@ def test_bad_descriptors_are_rejected_without_a_gpu():
     assert L.hands_conv2d_nhwc_f32(ctypes.byref(d), 16, 16, 16, None, 16, None) == 10001
     assert L.hands_conv2d_nhwc_f32(None, 16, 16, 16, None, 16, None) == 10001
     assert L.hands_maxpool3x3s2_nhwc_f32(16, 16, 1, 8, 8, 6, None) == 10001
+    # output map larger than the (H, W, stride, pad) geometry allows -> would read outside the input
+    d = _lib.ConvDesc(1, 7, 7, 16, 9, 9, 64, 1, 1, 1, 0, 16, 64, 0, 16, 0)
+    assert L.hands_conv2d_nhwc_f32(ctypes.byref(d), 16, 16, 16, None, 16, None) == 10001
+    d = _lib.ConvDesc(1, 7, 7, 16, 4, 4, 64, 1, 1, 2, 0, 16, 64, 0, 16, 0)       # stride 2: 4x4 is legal ...
+    d5 = _lib.ConvDesc(1, 7, 7, 16, 5, 5, 64, 1, 1, 2, 0, 16, 64, 0, 16, 0)      # ... 5x5 is not
+    assert L.hands_conv2d_nhwc_splitk_n_f32(ctypes.byref(d5), 16, 16, 16, None, 16, 2, 16, 1 << 20, None) == 10001
+    d = _lib.ConvDesc(70000, 224, 224, 16, 224, 224, 64, 1, 1, 1, 0, 16, 64, 0, 16, 0)   # > 2^31 elements
+    assert L.hands_conv2d_nhwc_f32(ctypes.byref(d), 16, 16, 16, None, 16, None) == 10001
     with pytest.raises(RuntimeError):
         _lib.check(10001, "x")
 
@@ -210,6 +218,19 @@ def test_load_reference_style_checkpoint(tmp_path, recipe_model):
     assert rep.missing_keys == [] and rep.unexpected_keys == ["mano_r.mano.unknown_smplx_buffer"]
     for k, v in recipe_model.state_dict().items():
         assert torch.equal(m.state_dict()[k], v), k
+    # a wrong-architecture checkpoint raises like the reference's load_state_dict (size mismatch), a
+    # MANO buffer of another shape is skipped, and a checkpoint without a single matching key raises too
+    wrong = dict(sd)
+    wrong["model.feature_conv.0.weight"] = torch.zeros(1024, 2048, 1, 1)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        load_reference_checkpoint(hands_amd.HandsLight(), {"state_dict": wrong})
+    pca = dict(sd)
+    pca["model.mano_r.mano.shapedirs"] = torch.zeros(778, 3, 45)
+    m3 = hands_amd.HandsLight()
+    load_reference_checkpoint(m3, {"state_dict": pca})
+    assert torch.equal(m3.mano_r.mano.shapedirs, recipe_model.mano_r.mano.shapedirs)
+    with pytest.raises(RuntimeError, match="no key"):
+        load_reference_checkpoint(hands_amd.HandsLight(), {"state_dict": {"model.foo": torch.zeros(1)}})
 
 
 def test_graphed_forward_and_frontend_refuse_cpu():
@@ -219,3 +240,112 @@ def test_graphed_forward_and_frontend_refuse_cpu():
         hands_amd.GraphedForward(None, {"img": torch.zeros(1, 3, 8, 8)}, {})
     with pytest.raises(RuntimeError):
         hands_amd.HandsFrontEnd().boxes(torch.zeros(1, 21, 2), torch.zeros(1, 21, 2), torch.eye(3)[None])
+
+
+# ---- real-asset loader (f3): chumpy-free MANO pickle reader -----------------------------------------
+def _write_fake_mano_pkl(path, asset, protocol=2):
+    """A pickle shaped like the licensed MANO_{RIGHT,LEFT}.pkl: a dict whose `shapedirs` (and here also
+    `v_template`, `posedirs`) are chumpy.ch.Ch objects -- a class NOT importable at load time --, whose
+    `J_regressor` is a scipy.sparse.csc_matrix, plus the keys smplx ignores."""
+    import pickle
+    import sys
+    import types
+    import scipy.sparse as sp
+
+    ch_mod = types.ModuleType("chumpy.ch")
+
+    class Ch(object):                          # chumpy.ch.Ch stores its value in the attribute `x`
+        def __init__(self, x):
+            self.x = np.asarray(x)
+            self._dirty_vars = set()
+            self._itr = None
+
+    Ch.__module__, Ch.__qualname__ = "chumpy.ch", "Ch"
+    ch_mod.Ch = Ch
+    pkg = types.ModuleType("chumpy")
+    pkg.ch = ch_mod
+    sys.modules["chumpy"], sys.modules["chumpy.ch"] = pkg, ch_mod
+    try:
+        d = {
+            "v_template": Ch(asset.v_template.astype(np.float64)),
+            "shapedirs": Ch(asset.shapedirs.astype(np.float64)),
+            "posedirs": Ch(asset.posedirs.T.reshape(778, 3, 135).astype(np.float64)),
+            "J_regressor": sp.csc_matrix(asset.J_regressor.astype(np.float64)),
+            "weights": asset.lbs_weights.astype(np.float64),
+            "hands_mean": asset.hands_mean.astype(np.float64),
+            "f": asset.faces.astype(np.uint32),
+            "kintree_table": np.stack([np.array([2 ** 32 - 1] + list(hands_amd.mano.PARENTS[1:]), dtype=np.int64),
+                                       np.arange(16)]),
+            "hands_components": np.eye(45), "hands_coeffs": np.zeros((10, 45)), "J": np.zeros((16, 3)),
+            "bs_style": "lbs", "bs_type": "lrotmin",
+        }
+        with open(path, "wb") as fh:
+            pickle.dump(d, fh, protocol=protocol)
+    finally:
+        del sys.modules["chumpy"], sys.modules["chumpy.ch"]
+
+
+@pytest.mark.parametrize("is_rhand", [True, False])
+def test_load_mano_pkl_without_chumpy(tmp_path, monkeypatch, is_rhand):
+    """hands_amd.mano.load_mano_pkl replaces smplx.MANO(model_path=$MANO_DIR, use_pca=False,
+    flat_hand_mean=False) (common/body_models.py:90-99): reads the chumpy / scipy-sparse pickle with
+    neither chumpy nor smplx installed and yields exactly the arrays the LBS kernels consume."""
+    import sys
+    from hands_amd.mano import build_mano_asset, load_mano_pkl, ManoLayer, SMPLX_MANO_BUFFERS
+    assert "chumpy" not in sys.modules
+    ref = hands_amd.synthetic_mano_asset(is_rhand)
+    fn = tmp_path / ("MANO_RIGHT.pkl" if is_rhand else "MANO_LEFT.pkl")
+    _write_fake_mano_pkl(str(fn), ref)
+    assert b"chumpy" in open(fn, "rb").read()
+    got = load_mano_pkl(str(fn), is_rhand)
+    assert "chumpy" not in sys.modules
+    for name in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "hands_mean"):
+        a, b = getattr(got, name), getattr(ref, name)
+        assert a.dtype == np.float32 and a.shape == b.shape and np.array_equal(a, b), name
+    assert got.faces.dtype == np.int64 and np.array_equal(got.faces, ref.faces)          # bit-exact face indices
+    assert got.is_rhand == is_rhand
+    # $MANO_DIR route (what the constructors use) + the smplx buffer names on the module
+    monkeypatch.setenv("MANO_DIR", str(tmp_path))
+    monkeypatch.delenv("HANDS_SYNTHETIC_MANO", raising=False)
+    via_env = build_mano_asset(is_rhand)
+    assert np.array_equal(via_env.posedirs, ref.posedirs)
+    layer = ManoLayer(via_env)
+    assert tuple(layer.state_dict().keys()) == SMPLX_MANO_BUFFERS
+    assert layer.state_dict()["posedirs"].shape == (135, 2334) and layer.state_dict()["faces_tensor"].dtype == torch.int64
+    assert torch.equal(layer.state_dict()["pose_mean"][3:], layer.state_dict()["hand_mean"])
+    back = layer.asset()
+    assert np.array_equal(back.hands_mean, ref.hands_mean) and np.array_equal(back.faces, ref.faces)
+    # the other side's file is missing and the synthetic stand-in was not asked for: fail like the reference
+    with pytest.raises(FileNotFoundError, match="MANO"):
+        build_mano_asset(not is_rhand)
+    assert build_mano_asset(not is_rhand, allow_synthetic=True).v_template.shape == (778, 3)
+
+
+def test_missing_assets_fail_loudly_without_opt_in(monkeypatch):
+    monkeypatch.delenv("HANDS_SYNTHETIC_MANO", raising=False)
+    monkeypatch.delenv("MANO_DIR", raising=False)
+    monkeypatch.delenv("DATA_DIR", raising=False)
+    with pytest.raises(FileNotFoundError):
+        hands_amd.HandsLight()
+    from hands_amd.hamer import load_mano_mean_params
+    with pytest.raises(FileNotFoundError):
+        load_mano_mean_params()
+    assert load_mano_mean_params(allow_synthetic=True)["pose"].shape == (96,)
+
+
+def test_smplx_named_mano_buffers_load_from_a_reference_checkpoint(recipe_model):
+    """A reference checkpoint carries `mano_{r,l}.mano.<smplx buffer>` entries; same-named, same-shaped
+    buffers override the module's asset, smplx's extra parameters are reported as unexpected."""
+    from hands_amd.checkpoint import load_reference_checkpoint
+    from hands_amd.mano import SMPLX_MANO_BUFFERS
+    m = hands_amd.HandsLight()
+    own = {k for k in m.state_dict() if k.startswith("mano_r.mano.")}
+    assert own == {"mano_r.mano." + b for b in SMPLX_MANO_BUFFERS}
+    sd = {"model." + k: v.clone() for k, v in recipe_model.state_dict().items()}
+    sd["model.mano_r.mano.v_template"] = torch.full((778, 3), 0.5)
+    sd["model.mano_r.mano.betas"] = torch.zeros(1, 10)                       # smplx nn.Parameter
+    sd["model.mano_r.mano.vertex_joint_selector.extra_joints_idxs"] = torch.tensor([744, 320, 443, 554, 671])
+    rep = load_reference_checkpoint(m, {"state_dict": sd})
+    assert sorted(rep.unexpected_keys) == ["mano_r.mano.betas", "mano_r.mano.vertex_joint_selector.extra_joints_idxs"]
+    assert torch.all(m.mano_r.mano.v_template == 0.5) and m._packed is None
+    assert np.all(m.mano_r.mano.asset().v_template == 0.5)

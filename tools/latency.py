@@ -1,5 +1,6 @@
-import sys, time, torch
+import os, sys, time, torch
 sys.path.insert(0, ".")
+os.environ.setdefault("HANDS_SYNTHETIC_MANO", "1")
 import hands_amd
 from hands_amd.weights import synthetic_inputs
 dev = torch.device("cuda:0")
