@@ -3,9 +3,14 @@ the predictions per forward (RCCL over xGMI on the GPU box, gloo in the CPU test
 
 The reference has no inference-side collective (Lightning DDP is training
 only); samples are independent (eval BatchNorm, no cross-sample op), so ranks exchange nothing
-until the end, where the 22 prediction tensors are packed into ONE (bz_local, D) fp32 buffer and
+until the end, where the 22 prediction tensors are packed into ONE (rows, D) fp32 buffer and
 gathered with a single collective -- 20.5 KB per hand, so a direct all-gather keeps all 7 xGMI
 links of a GPU busy instead of 22 small ring steps.
+
+Uneven shards (``bz % world != 0``): every rank pads its packed buffer to ``ceil(bz / world)`` rows,
+so the collective always moves equal counts (RCCL hangs or corrupts rows on mismatched counts), and
+the padding rows are trimmed after the gather with the same ``shard_range`` arithmetic.  A rank whose
+shard is empty (``bz < world``) runs the forward on sample 0 and contributes zero valid rows.
 """
 from __future__ import annotations
 
@@ -22,9 +27,18 @@ def shard_range(bz: int, rank: int, world: int):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def max_shard(bz: int, world: int) -> int:
+    return -(-bz // world)
+
+
 def shard_batch(inputs: dict, meta_info: dict, rank: int, world: int):
-    bz = inputs["img"].shape[0]
+    """This rank's slice of every per-sample entry.  An empty shard is replaced by sample 0 (its rows
+    are discarded by :func:`gather_predictions`), so the model never sees a zero-sized batch."""
+    bz = inputs["img"].shape[0] if "img" in inputs else next(
+        v.shape[0] for v in inputs.values() if isinstance(v, torch.Tensor) and v.ndim >= 1)
     lo, hi = shard_range(bz, rank, world)
+    if hi == lo:
+        lo, hi = 0, 1
 
     def cut(v):
         if isinstance(v, torch.Tensor) and v.ndim >= 1 and v.shape[0] == bz:
@@ -36,13 +50,19 @@ def shard_batch(inputs: dict, meta_info: dict, rank: int, world: int):
     return {k: cut(v) for k, v in inputs.items()}, {k: cut(v) for k, v in meta_info.items()}
 
 
-def pack_predictions(out: dict):
-    """(bz, D) fp32 buffer + the layout needed to unpack it."""
+def pack_predictions(out: dict, rows: int | None = None):
+    """(rows, D) fp32 buffer + the layout needed to unpack it; ``rows`` > local batch pads with zeros."""
     keys = list(out.keys())
     bz = out[keys[0]].shape[0]
     layout = [(k, tuple(out[k].shape[1:])) for k in keys]
-    flat = torch.cat([out[k].reshape(bz, -1).to(torch.float32) for k in keys], dim=1).contiguous()
-    return flat, layout
+    width = lambda shp: int(torch.Size(shp).numel())       # explicit: reshape(0, -1) is ambiguous
+    flat = torch.cat([out[k].reshape(bz, width(shp)).to(torch.float32) for k, shp in layout], dim=1)
+    if rows is not None and rows != bz:
+        assert rows > bz
+        padded = flat.new_zeros((rows, flat.shape[1]))
+        padded[:bz] = flat
+        flat = padded
+    return flat.contiguous(), layout
 
 
 def unpack_predictions(flat: torch.Tensor, layout) -> xdict:
@@ -58,27 +78,48 @@ def unpack_predictions(flat: torch.Tensor, layout) -> xdict:
     return res
 
 
-def gather_predictions(out: dict, group=None) -> xdict:
-    """All-gather every rank's prediction dict (equal local batch sizes) into the global one."""
+def gather_predictions(out: dict, group=None, global_bz: int | None = None) -> xdict:
+    """All-gather every rank's prediction dict into the global one (rank order = sample order).
+
+    ``global_bz=None``: every rank holds the same number of rows (weak-scaling benchmark).  Otherwise
+    the ranks hold the ``shard_range(global_bz, rank, world)`` shards (possibly uneven or empty): buffers
+    are padded to the largest shard before the collective and trimmed after it."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return xdict(out)
     world = dist.get_world_size(group)
-    flat, layout = pack_predictions(out)
+    rows = None if global_bz is None else max_shard(global_bz, world)
+    flat, layout = pack_predictions(out, rows)
     full = torch.empty((world * flat.shape[0], flat.shape[1]), dtype=flat.dtype, device=flat.device)
     try:
         dist.all_gather_into_tensor(full, flat, group=group)
-    except (RuntimeError, NotImplementedError):
+    except NotImplementedError:        # a backend without the single-buffer form: same bytes, list form
         parts = [torch.empty_like(flat) for _ in range(world)]
         dist.all_gather(parts, flat, group=group)
         full = torch.cat(parts, 0)
+    if global_bz is not None:
+        keep = []
+        for r in range(world):
+            lo, hi = shard_range(global_bz, r, world)
+            keep.append(full[r * rows: r * rows + (hi - lo)])
+        full = torch.cat(keep, 0) if len(keep) > 1 else keep[0]
+        assert full.shape[0] == global_bz
     return unpack_predictions(full, layout)
 
 
-def data_parallel_forward(model, inputs, meta_info, group=None) -> xdict:
-    """Shard the global batch over the ranks, run the local forward, gather the predictions."""
+def data_parallel_forward(model, inputs, meta_info, group=None, gather_on_host=False) -> xdict:
+    """Shard the global batch over the ranks, run the local forward, gather the predictions.
+    ``gather_on_host``: move the local predictions to the CPU first (gloo dry runs of the GPU path)."""
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:
         rank, world = 0, 1
+    bz = inputs["img"].shape[0] if "img" in inputs else next(
+        v.shape[0] for v in inputs.values() if isinstance(v, torch.Tensor) and v.ndim >= 1)
     li, lm = shard_batch(inputs, meta_info, rank, world)
-    return gather_predictions(model(li, lm), group)
+    out = model(li, lm)
+    lo, hi = shard_range(bz, rank, world)
+    if world > 1 and hi - lo != next(iter(out.values())).shape[0]:      # empty shard: drop the stand-in row
+        out = {k: v[: hi - lo] for k, v in out.items()}
+    if gather_on_host:
+        out = {k: v.cpu() for k, v in out.items()}
+    return gather_predictions(out, group, global_bz=bz if world > 1 else None)

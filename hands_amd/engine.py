@@ -1,0 +1,141 @@
+"""Per-model launch state of the GEMM / convolution kernel (``hands_conv2d_nhwc_f32`` and friends).
+
+Every model (``HandsLight``, ``HAMER``, ``HandOccNet``) owns one :class:`ConvEngine`: the switches that
+used to be class attributes (split-K policy, small-batch ``latency_mode``, multi-stream overlap, the
+stem / downsample fusions, the profiling hook) are per-instance state, so two models in one process can
+differ and the C library underneath keeps its "no global mutable state" promise all the way up.
+``DEFAULT_ENGINE`` serves the few call sites that have no model (tests and tools driving a single layer,
+the wrapper's ground-truth MANO pass).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._lib import ConvDesc, check, ptr
+
+
+class ConvEngine:
+    def __init__(self):
+        self.use_splitk = True        # deterministic split-K for the latency-bound per-sample head GEMMs
+        self.latency_mode = False     # opt-in small-batch serving: split-K on every launch with <= 128 output
+                                      # tiles (results then depend on the batch size at the 1e-7 level; the
+                                      # default keeps every output bit independent of the batch size)
+        self.overlap = True           # run independent jobs (trunks, heads, crop chunks) on side HIP streams
+        self.fuse_stem_pool = True    # stem conv + BN + act + max-pool as one kernel (csrc/stem_pool.hip)
+        self.fuse_downsample = True   # first block of a stage: conv3 + downsample + add + ReLU as one two-source GEMM
+        self.hook = None              # callable(phase, pc, npix, stream_handle, has_res, kernel): bench.py brackets
+                                      # every MFMA launch (conv_igemm and the fused stem) with events
+        self._splitk_ws = {}          # (device, stream handle) -> workspace tensor
+
+    def clone_settings(self) -> "ConvEngine":
+        e = ConvEngine()
+        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample"):
+            setattr(e, k, getattr(self, k))
+        return e
+
+    def _workspace(self, dev, stream, need):
+        key = (dev, stream)
+        ws = self._splitk_ws.get(key)
+        if ws is None or ws.numel() < need:
+            if ws is not None:
+                # a kernel on a raw side-stream handle may still read the old block, and the caching
+                # allocator only knows torch's current stream: drain before dropping it (growth is rare --
+                # the first forward at a new batch size)
+                torch.cuda.synchronize(dev)
+            ws = self._splitk_ws[key] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=dev)
+        return ws
+
+    def conv(self, L, pc, x, B, H, W, out, relu, stream, res=None, in_ps=None, out_ps=None, res_ps=None,
+             x_off=0, out_off=0, res_off=0, splitk=False, splitk_n=0):
+        """One convolution / linear layer.  ``splitk=True`` marks rows that are per-SAMPLE (head MLPs): only
+        there may the library cut K by its own (layer-only) policy -- token / pixel GEMMs would cross the
+        library's row threshold between batch sizes and lose bit-reproducibility.  ``splitk_n`` is a
+        call-site constant slice count (summation order independent of the batch size)."""
+        Ho = (H + 2 * pc.pad - pc.KH) // pc.stride + 1
+        Wo = (W + 2 * pc.pad - pc.KW) // pc.stride + 1
+        d = ConvDesc(B, H, W, pc.Cin, Ho, Wo, pc.Cout, pc.KH, pc.KW, pc.stride, pc.pad,
+                     in_ps or pc.Cin, out_ps or pc.Cout,
+                     (pc.Cout if res_ps is None else res_ps) if res is not None else 0,
+                     pc.Kpad, int(relu))   # relu: bool or a HANDS_ACT_* code
+        hook = self.hook
+        if hook is not None:
+            hook("begin", pc, B * Ho * Wo, stream, res is not None, "conv_igemm_f32_kernel")
+        S = L.hands_conv2d_splitk_factor(C.byref(d)) if (splitk and self.use_splitk) else 1
+        if splitk_n > 1 and self.use_splitk:
+            S = splitk_n
+        if self.latency_mode:
+            # small-batch serving: a layer with a handful of output tiles walks a K of 2304-4608 serially
+            # on a few CUs; cut K so that ~256 workgroups exist, at least 8 k-steps (128 floats) per slice
+            bm, bn = (256, 64) if pc.Cout <= 64 else (128, 128)
+            tiles = -(-(B * Ho * Wo) // bm) * -(-pc.Cout // bn)
+            S = max(S, min(256 // tiles, pc.Kpad // 128, 32)) if tiles <= 128 else S
+        if S > 1:     # latency-bound GEMM: deterministic split-K with a per-stream workspace
+            ws = self._workspace(x.device, stream, S * B * Ho * Wo * pc.Cout)
+            check(L.hands_conv2d_nhwc_splitk_n_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
+                                                   ptr(res, res_off) if res is not None else None, ptr(out, out_off),
+                                                   S, ptr(ws), ws.numel(), stream), "hands_conv2d_nhwc_splitk_n_f32")
+        else:
+            check(L.hands_conv2d_nhwc_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
+                                          ptr(res, res_off) if res is not None else None, ptr(out, out_off),
+                                          stream), "hands_conv2d_nhwc_f32")
+        if hook is not None:
+            hook("end", pc, B * Ho * Wo, stream, res is not None, "conv_igemm_f32_kernel")
+        return Ho, Wo
+
+    def conv_dual(self, L, pc, split, x, x2, B, Ho, Wo, H2, W2, out, stream, act=1):
+        """act(conv3(x) + downsample(x2)) (resnet.py:146-154) with the identity never materialised."""
+        K0, K1, stride2 = split
+        d = ConvDesc(B, Ho, Wo, K0, Ho, Wo, pc.Cout, 1, 1, 1, 0, K0, pc.Cout, 0, pc.Kpad, int(act))
+        hook = self.hook
+        if hook is not None:
+            hook("begin", pc, B * Ho * Wo, stream, False, "conv_igemm_f32_kernel")
+        check(L.hands_conv1x1_dual_nhwc_f32(C.byref(d), ptr(x), ptr(x2), K1, H2, W2, stride2, K1, ptr(pc.w), ptr(pc.bias),
+                                            ptr(out), stream), "hands_conv1x1_dual_nhwc_f32")
+        if hook is not None:
+            hook("end", pc, B * Ho * Wo, stream, False, "conv_igemm_f32_kernel")
+
+    def stem_pool(self, L, pc, x4, x_off, out, B, H, W, act, stream):
+        """conv 7x7/2 + folded BN + act + max-pool 3x3/2 in one kernel (resnet.py:264-268); the conv map
+        (B, Hc, Wc, 64) never reaches HBM.  Returns the conv map size (Hc, Wc)."""
+        Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        hook = self.hook
+        if hook is not None:
+            hook("begin", pc, B * Hc * Wc, stream, False, "stem_pool_kernel")
+        check(L.hands_stem_conv_maxpool_nhwc_f32(ptr(x4, x_off), ptr(pc.w), ptr(pc.bias), ptr(out), B, H, W, int(act), stream),
+              "hands_stem_conv_maxpool_nhwc_f32")
+        if hook is not None:
+            hook("end", pc, B * Hc * Wc, stream, False, "stem_pool_kernel")
+        return Hc, Wc
+
+
+DEFAULT_ENGINE = ConvEngine()
+
+
+class EngineSwitches:
+    """Mixin: per-instance views of the engine switches under the names the models always used."""
+
+    @property
+    def latency_mode(self):
+        return self.engine.latency_mode
+
+    @latency_mode.setter
+    def latency_mode(self, v):
+        self.engine.latency_mode = bool(v)
+
+    @property
+    def overlap_trunks(self):
+        return self.engine.overlap
+
+    @overlap_trunks.setter
+    def overlap_trunks(self, v):
+        self.engine.overlap = bool(v)
+
+    @property
+    def conv_hook(self):
+        return self.engine.hook
+
+    @conv_hook.setter
+    def conv_hook(self, fn):
+        self.engine.hook = fn

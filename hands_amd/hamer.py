@@ -31,7 +31,8 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, check, ptr
-from .hands_light import HandsLight, MANOHead, _Args, mano_consts, run_mano_heads
+from .engine import ConvEngine, EngineSwitches
+from .hands_light import MANOHead, _Args, mano_consts, run_mano_heads
 from .packing import pack_conv, pack_linear, pack_mano
 from .weights import synthetic_mano_mean_params
 from .xdict import xdict
@@ -178,7 +179,7 @@ HAMER_DEFAULT_ARGS = _Args(pos_enc="center+corner_latent", n_freq_pos_enc=4, use
                            method="hamer_light")
 
 
-class HAMER(nn.Module):
+class HAMER(EngineSwitches, nn.Module):
     def __init__(self, args=None, focal_length=1000.0, img_res=224, mano_assets=None, mean_params=None):
         super().__init__()
         args = args if args is not None else HAMER_DEFAULT_ARGS
@@ -204,6 +205,8 @@ class HAMER(nn.Module):
         self.img_res, self.focal_length = img_res, focal_length
         self._packed = None
         self._packed_dev = None
+        self.engine = ConvEngine()
+        self.chunks = 2   # the 2*bz crops run as this many jobs on separate HIP streams (1 = single stream)
         self._ws = {}
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_packed())
 
@@ -266,8 +269,6 @@ class HAMER(nn.Module):
             self._packed_dev = dev
         return self._packed
 
-    chunks = 2   # the 2*bz crops run as this many jobs on separate HIP streams (1 = single stream)
-
     def _side_stream(self, dev, i):
         key = ("side_stream", i)
         st = self._ws.get(key)
@@ -298,7 +299,7 @@ class HAMER(nn.Module):
         P = self.packed(dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         buf = lambda n, numel: self._buf(n, numel, dev)
-        gemm = lambda pc, x, rows, out, act=ACT_NONE, **kw: HandsLight._conv(L, pc, x, rows, 1, 1, out, act, stream, **kw)
+        gemm = lambda pc, x, rows, out, act=ACT_NONE, **kw: self.engine.conv(L, pc, x, rows, 1, 1, out, act, stream, **kw)
         hgemm = lambda *a, **kw: gemm(*a, splitk=True, **kw)     # per-sample rows: latency-bound head GEMMs
         lnorm = lambda x, gb, out, rows, Cc, eps, addvec=None, rpv=1: check(
             L.hands_layernorm_f32(ptr(x), ptr(gb[0]), ptr(gb[1]), ptr(out), ptr(addvec), rpv, rows, Cc, eps, stream),
@@ -331,13 +332,13 @@ class HAMER(nn.Module):
             sh = st.cuda_stream
             Mc = nB * T
             cbuf = lambda n, numel: self._buf(f"{n}@{tag}", numel, dev)
-            gemm = lambda pc, x, rows, out, act=ACT_NONE, **kw: HandsLight._conv(L, pc, x, rows, 1, 1, out, act, sh, **kw)
+            gemm = lambda pc, x, rows, out, act=ACT_NONE, **kw: self.engine.conv(L, pc, x, rows, 1, 1, out, act, sh, **kw)
             hgemm = lambda *a, **kw: gemm(*a, splitk=True, **kw)
             lnorm = lambda x, gb, out, rows, Cc, eps, addvec=None, rpv=1: check(
                 L.hands_layernorm_f32(ptr(x), ptr(gb[0]), ptr(gb[1]), ptr(out), addvec, rpv, rows, Cc, eps, sh), "layernorm")
             # ViT-H/16 (vit.py:320-342)
             x = cbuf("vit_x", Mc * Cd)
-            ho, wo = HandsLight._conv(L, P["patch"], x4, nB, S, Wc, x, ACT_NONE, sh, x_off=lo * S * Wc * 4)
+            ho, wo = self.engine.conv(L, P["patch"], x4, nB, S, Wc, x, ACT_NONE, sh, x_off=lo * S * Wc * 4)
             assert (ho, wo) == (TOKENS_H, TOKENS_W)
             check(L.hands_add_pos_f32(ptr(x), ptr(P["pos"]), ptr(kpe, lo * Cd), nB, T, Cd, sh), "add_pos")
             y, qkv, att, hid = cbuf("vit_y", Mc * Cd), cbuf("vit_qkv", Mc * 3 * Cd), cbuf("vit_att", Mc * Cd), cbuf("vit_h", Mc * 4 * Cd)
@@ -372,7 +373,7 @@ class HAMER(nn.Module):
             hgemm(P["decout"], xd, nB, pred, res=P["init"], res_ps=0, out_off=lo * 112)   # dec*(token) + mean params
 
         main = torch.cuda.current_stream(dev)
-        nch = HAMER.chunks if HandsLight.overlap_trunks else 1
+        nch = self.chunks if self.engine.overlap else 1
         nch = max(1, min(nch, B2))
         if nch == 1:
             pipeline(0, B2, main, "c0")
@@ -399,7 +400,7 @@ class HAMER(nn.Module):
         cam = pred[:, 108:111].contiguous()
         # -- MANOHead x2 (model.py:125-129) ----------------------------------------------------------
         output = run_mano_heads(L, P["mano_r"], P["mano_l"], rot, shape, cam, cam, K, float(self.img_res), bz,
-                                stream, buf)
+                                stream, buf, self.engine)
         # -- grasp classifier (model.py:136-143) -----------------------------------------------------
         gld = P["g0"].Cin
         gin = buf("grasp_in", B2 * gld)

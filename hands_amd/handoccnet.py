@@ -24,7 +24,8 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import ACT_GELU, ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, check, ptr
-from .hands_light import HandsLight, MANOHead, _Args, mano_consts, run_mano_heads
+from .engine import ConvEngine, EngineSwitches
+from .hands_light import MANOHead, _Args, mano_consts, run_mano_heads
 from .packing import BN_EPS, PackedConv, pack_conv, pack_linear, pack_mano
 from .param_tree import build_tree, load_manifest
 from .xdict import xdict
@@ -35,28 +36,28 @@ HANDOCC_DEFAULT_ARGS = _Args(pos_enc="center+corner_latent", n_freq_pos_enc=4, u
 NTOK, CF, HEADS = 1024, 256, 4
 
 
-def _conv_fns(L, stream, new):
+def _conv_fns(L, stream, new, engine, small_map_splitk=True):
     """(conv, hconv) launchers bound to one HIP stream; hconv = per-sample rows (split-K head GEMMs)."""
     def conv(pc: PackedConv, x, B, H, W, act=ACT_NONE, res=None, out=None, **kw):
         Ho = (H + 2 * pc.pad - pc.KH) // pc.stride + 1
         Wo = (W + 2 * pc.pad - pc.KW) // pc.stride + 1
         out = out if out is not None else new(B, Ho, Wo, pc.Cout)
-        if HandOccNet.small_map_splitk and H * W > 1 and Ho * Wo <= 64 and "splitk" not in kw:
+        if small_map_splitk and H * W > 1 and Ho * Wo <= 64 and "splitk" not in kw:
             # 8x8 ... 2x2 maps (layer4, the deep hourglass / encoder levels): a handful of output tiles
             # walking K = 1152-4608 serially.  The slice count depends on the map size and K only, never
             # on the batch, so every output bit stays independent of the batch size.
             S = 4 if Ho * Wo > 16 else 8
             kw["splitk_n"] = max(1, min(S, pc.Kpad // 128))
-        elif (HandOccNet.small_map_splitk and H * W > 1 and Ho * Wo <= 256 and pc.Cout <= 128 and pc.Kpad >= 1024
+        elif (small_map_splitk and H * W > 1 and Ho * Wo <= 256 and pc.Cout <= 128 and pc.Kpad >= 1024
               and "splitk" not in kw):
             kw["splitk_n"] = 2          # 16x16 maps, one n-tile: 2 output tiles per crop
-        HandsLight._conv(L, pc, x, B, H, W, out, act, stream, res=res, **kw)
+        engine.conv(L, pc, x, B, H, W, out, act, stream, res=res, **kw)
         return out, Ho, Wo
 
     return conv, (lambda *a, **kw: conv(*a, splitk=True, **kw))
 
 
-class HandOccNet(nn.Module):
+class HandOccNet(EngineSwitches, nn.Module):
     def __init__(self, focal_length=1000.0, img_res=224, args=None, mano_assets=None):
         super().__init__()
         args = args if args is not None else HANDOCC_DEFAULT_ARGS
@@ -81,10 +82,10 @@ class HandOccNet(nn.Module):
         self.img_res, self.focal_length = img_res, focal_length
         self._packed = None
         self._packed_dev = None
+        self.engine = ConvEngine()
+        self.small_map_splitk = True   # call-site constant split-K on maps of <= 8x8 pixels (see _conv_fns)
+        self.chunks = 2   # the 2*bz crops run as this many jobs on separate HIP streams (1 = single stream)
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_packed())
-
-    small_map_splitk = True   # call-site constant split-K on maps of <= 8x8 pixels (see _conv_fns)
-    chunks = 2   # the 2*bz crops run as this many jobs on separate HIP streams (1 = single stream)
 
     def _side_stream(self, dev, i):
         key = ("side_stream", i)
@@ -229,13 +230,13 @@ class HandOccNet(nn.Module):
         center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
         corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0)
 
-        conv, hconv = _conv_fns(L, stream, new)
+        conv, hconv = _conv_fns(L, stream, new, self.engine, self.small_map_splitk)
 
         def pipeline(x4, center, corner, B2, stream):
             """Everything per crop, from the NHWC image to the 112-vector of the regressor; rows are
             independent, so the 2*bz crops may be cut into chunks that run on separate HIP streams."""
             npix = B2 * NTOK
-            conv, hconv = _conv_fns(L, stream, new)
+            conv, hconv = _conv_fns(L, stream, new, self.engine, self.small_map_splitk)
             enc = new(B2, P["kpe0"].Cin)
             check(L.hands_kpe_encode_f32(ptr(center), ptr(corner), ptr(enc), B2, P["kpe0"].Cin, self.n_freq, stream), "kpe")
             k1, _, _ = conv(P["kpe0"], enc, B2, 1, 1, ACT_RELU)
@@ -245,9 +246,8 @@ class HandOccNet(nn.Module):
             H, W = (S - 1) // 2 + 1, (S - 1) // 2 + 1
             Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
             cur = new(B2, Hp, Wp, 64)
-            if HandsLight.fuse_stem_pool:         # conv + BN + LeakyReLU + max-pool in one kernel (bit-identical)
-                check(L.hands_stem_conv_maxpool_nhwc_f32(ptr(x4), ptr(P["stem"].w), ptr(P["stem"].bias), ptr(cur), B2, S, S,
-                                                         ACT_LEAKY_RELU, stream), "hands_stem_conv_maxpool_nhwc_f32")
+            if self.engine.fuse_stem_pool:         # conv + BN + LeakyReLU + max-pool in one kernel (bit-identical)
+                self.engine.stem_pool(L, P["stem"], x4, 0, cur, B2, S, S, ACT_LEAKY_RELU, stream)
             else:
                 a, H, W = conv(P["stem"], x4, B2, S, S, ACT_LEAKY_RELU)
                 check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(cur), B2, H, W, 64, stream), "maxpool")
@@ -384,7 +384,7 @@ class HandOccNet(nn.Module):
         main = torch.cuda.current_stream(dev)
         # measured (bz=32 -> 64 crops): 2 chunks without split-K lose 8 % (smaller launches), with
         # latency_mode they gain 4 %; at 512 crops they gain 3 %
-        nch = HandOccNet.chunks if (dbg is None and HandsLight.overlap_trunks and (B2 >= 128 or HandsLight.latency_mode)) else 1
+        nch = self.chunks if (dbg is None and self.engine.overlap and (B2 >= 128 or self.engine.latency_mode)) else 1
         nch = max(1, min(nch, B2))
         if nch == 1:
             pred = pipeline(x4, center, corner, B2, stream)
@@ -424,7 +424,7 @@ class HandOccNet(nn.Module):
                 ws[name] = new(numel)
             return ws[name]
 
-        output = run_mano_heads(L, P["mano_r"], P["mano_l"], rot, shape, cam, cam, K, float(self.img_res), bz, stream, buf)
+        output = run_mano_heads(L, P["mano_r"], P["mano_l"], rot, shape, cam, cam, K, float(self.img_res), bz, stream, buf, self.engine)
         gld = P["g0"].Cin
         gin = new(B2, gld)
         check(L.hands_grasp_input_f32(ptr(shape), 10, ptr(rot), ptr(shape), ptr(gin), B2, bz, 0, gld, stream), "grasp_in")

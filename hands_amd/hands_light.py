@@ -28,7 +28,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import ConvDesc, ManoConsts, ManoOut, check, ptr
+from ._lib import ManoConsts, ManoOut, check, ptr
+from .engine import DEFAULT_ENGINE, ConvEngine, EngineSwitches
 from .mano import ManoLayer, build_mano_asset
 from .packing import (HMR_VEC, PackedConv, fold_bn, hmr_state_columns, pack_conv, pack_linear,
                       pack_mano)
@@ -112,7 +113,7 @@ class MANOHead(nn.Module):
         return self.mano.faces
 
 
-def run_mano_heads(L, mano_r, mano_l, rot, shape, cam, cam_init, K, img_res, bz, stream, buf):
+def run_mano_heads(L, mano_r, mano_l, rot, shape, cam, cam_init, K, img_res, bz, stream, buf, engine=None):
     """MANOHead.forward for the right (rows [0,bz)) and left (rows [bz,2bz)) hands
     (src/nets/hand_heads/mano_head.py:21-65) + the `cam_t.wp.init` / `mano.` prefixing of
     model.py:392-399.  rot (2bz,16,3,3), shape (2bz,10), cam / cam_init (2bz,3), K (bz,3,3)."""
@@ -125,7 +126,7 @@ def run_mano_heads(L, mano_r, mano_l, rot, shape, cam, cam_init, K, img_res, bz,
         ro = side * bz
         check(L.hands_mano_pose_f32(C.byref(mp["consts"]), ptr(rot, ro * 144), ptr(shape, ro * 10), 10,
                                     ptr(blend_in), 160, ptr(Abuf), ptr(j16), bz, stream), "mano_pose")
-        HandsLight._conv(L, mp["blend"], blend_in, bz, 1, 1, vposed, False, stream)
+        (engine or DEFAULT_ENGINE).conv(L, mp["blend"], blend_in, bz, 1, 1, vposed, False, stream)
         o = {"vertices": torch.empty(bz, 778, 3, device=dev), "joints3d": torch.empty(bz, 21, 3, device=dev),
              "v3d.cam": torch.empty(bz, 778, 3, device=dev), "j3d.cam": torch.empty(bz, 21, 3, device=dev),
              "j2d.norm": torch.empty(bz, 21, 2, device=dev), "cam_t": torch.empty(bz, 3, device=dev)}
@@ -172,10 +173,24 @@ DEFAULT_ARGS = _Args(backbone="resnet50", pos_enc="center+corner_latent", n_freq
 
 
 # --------------------------------------------------------------------------------------------------
-class HandsLight(nn.Module):
+class _PackedHolder:
+    """Packed (kernel-layout) weights of one parameter set, shared by a model and its replicas: any of them
+    invalidating it (load_state_dict, .to(), invalidate_packed) makes all of them repack on the next forward."""
+
+    def __init__(self):
+        self.packed, self.dev, self.version = None, None, 0
+
+    def invalidate(self):
+        self.packed = None
+        self.version += 1
+
+
+class HandsLight(EngineSwitches, nn.Module):
     def __init__(self, backbone="resnet50", focal_length=1000.0, img_res=224, args=None,
                  mano_assets=None):
         super().__init__()
+        self.engine = ConvEngine()
+        self.trunk_chunks = (1, 2)    # (global, hand) trunk jobs, one HIP stream each
         args = args if args is not None else DEFAULT_ARGS
         get = (lambda k, d=None: args.get(k, d)) if hasattr(args, "get") else (lambda k, d=None: getattr(args, k, d))
         self.args = args
@@ -218,14 +233,19 @@ class HandsLight(nn.Module):
         self.mode = "train"
         self.img_res = img_res
         self.focal_length = focal_length
-        self._packed = None
-        self._packed_dev = None
+        self._holder = _PackedHolder()
         self._ws = {}
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_packed())
 
     # ---- packing ------------------------------------------------------------------------------
+    @property
+    def _packed(self):
+        return self._holder.packed
+
     def invalidate_packed(self):
-        self._packed = None
+        """Drop the packed weights (shared with every replica): call after writing parameters IN PLACE
+        (``load_state_dict`` and ``.to()`` do it themselves; ``apply_recipe`` calls it)."""
+        self._holder.invalidate()
         self._ws = {}
 
     def _apply(self, fn, *a, **k):
@@ -306,21 +326,24 @@ class HandsLight(nn.Module):
         return P
 
     def replica(self):
-        """A second handle on the SAME parameters and packed weights with its own workspaces and side
-        streams, for a second request stream: two forwards in flight (one per torch stream, one replica
-        each) overlap the 3 ms tail of one with the trunks of the other (+2 % throughput measured).
-        Plain PyTorch stream semantics: each forward's outputs are valid on the stream it was called on."""
+        """A second handle on the SAME parameters and packed weights with its own workspaces, side
+        streams and engine switches, for a second request stream: two forwards in flight (one per torch
+        stream, one replica each) overlap the tail of one with the trunks of the other.  Plain PyTorch
+        stream semantics: each forward's outputs are valid on the stream it was called on.  The packed
+        weights live in a holder both share, so ``load_state_dict`` / ``.to()`` / ``invalidate_packed`` on
+        either one is seen by both."""
         self.packed(next(self.parameters()).device)
         import copy
         r = copy.copy(self)
         r._ws = {}
+        r.engine = self.engine.clone_settings()
         return r
 
     def packed(self, dev):
-        if self._packed is None or self._packed_dev != dev:
-            self._packed = self._pack(dev)
-            self._packed_dev = dev
-        return self._packed
+        h = self._holder
+        if h.packed is None or h.dev != dev:
+            h.packed, h.dev = self._pack(dev), dev
+        return h.packed
 
     # ---- buffers ------------------------------------------------------------------------------
     def _side_stream(self, dev, name="side_stream"):
@@ -338,70 +361,9 @@ class HandsLight(nn.Module):
         return t
 
     # ---- kernel launch helpers ----------------------------------------------------------------
-    conv_hook = None   # bench.py installs a callback here to bracket every GEMM launch with events
-    use_splitk = True       # deterministic split-K for the latency-bound head GEMMs
-    latency_mode = False    # opt-in small-batch serving mode: split-K on every layer with <= 128 output tiles
-                            # (results then depend on the batch size at the 1e-7 level; the default keeps
-                            # every output bit independent of the batch size)
-    _splitk_ws = {}         # (device, stream) -> workspace tensor
-    overlap_trunks = True   # run the global trunk on a second HIP stream beside the hand trunk
-    trunk_chunks = (1, 2)   # (global, hand) trunk jobs, one HIP stream each
-
-    @staticmethod
-    def _conv(L, pc: PackedConv, x, B, H, W, out, relu, stream, res=None, in_ps=None, out_ps=None,
-              res_ps=None, x_off=0, out_off=0, res_off=0, splitk=False, splitk_n=0):
-        Ho = (H + 2 * pc.pad - pc.KH) // pc.stride + 1
-        Wo = (W + 2 * pc.pad - pc.KW) // pc.stride + 1
-        d = ConvDesc(B, H, W, pc.Cin, Ho, Wo, pc.Cout, pc.KH, pc.KW, pc.stride, pc.pad,
-                     in_ps or pc.Cin, out_ps or pc.Cout,
-                     (pc.Cout if res_ps is None else res_ps) if res is not None else 0,
-                     pc.Kpad, int(relu))   # relu: bool or a HANDS_ACT_* code
-        hook = HandsLight.conv_hook
-        if hook is not None:
-            hook("begin", pc, B * Ho * Wo, stream, res is not None)
-        # split-K only where the caller says the rows are per-SAMPLE (head MLPs): token / pixel GEMMs
-        # would cross the library's row threshold between batch sizes and lose bit-reproducibility
-        S = L.hands_conv2d_splitk_factor(C.byref(d)) if (splitk and HandsLight.use_splitk) else 1
-        if splitk_n > 1 and HandsLight.use_splitk:
-            S = splitk_n      # call-site constant: the summation order stays independent of the batch size
-        if HandsLight.latency_mode:
-            # small-batch serving: a layer with a handful of output tiles walks a K of 2304-4608 serially
-            # on a few CUs; cut K so that ~256 workgroups exist, at least 8 k-steps (128 floats) per slice
-            bm, bn = (256, 64) if pc.Cout <= 64 else (128, 128)
-            tiles = -(-(B * Ho * Wo) // bm) * -(-pc.Cout // bn)
-            S = max(S, min(256 // tiles, pc.Kpad // 128, 32)) if tiles <= 128 else S
-        if S > 1:     # latency-bound GEMM: deterministic split-K with a per-stream workspace
-            need = S * B * Ho * Wo * pc.Cout
-            key = (x.device, stream)
-            ws = HandsLight._splitk_ws.get(key)
-            if ws is None or ws.numel() < need:
-                ws = HandsLight._splitk_ws[key] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=x.device)
-            check(L.hands_conv2d_nhwc_splitk_n_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
-                                                   ptr(res, res_off) if res is not None else None, ptr(out, out_off),
-                                                   S, ptr(ws), ws.numel(), stream), "hands_conv2d_nhwc_splitk_n_f32")
-        else:
-            check(L.hands_conv2d_nhwc_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
-                                          ptr(res, res_off) if res is not None else None, ptr(out, out_off),
-                                          stream), "hands_conv2d_nhwc_f32")
-        if hook is not None:
-            hook("end", pc, B * Ho * Wo, stream, res is not None)
-        return Ho, Wo
-
-    fuse_stem_pool = True   # stem conv + BN + ReLU + max-pool as one kernel (csrc/stem_pool.hip)
-    fuse_downsample = True  # first block of each stage: conv3 + downsample + add + ReLU as one two-source GEMM
-
-    @staticmethod
-    def _conv_dual(L, pc: PackedConv, split, x, x2, B, Ho, Wo, H2, W2, out, stream, act=1):
-        """act(conv3(x) + downsample(x2)) (resnet.py:146-154) with the identity never materialised."""
-        K0, K1, stride2 = split
-        d = ConvDesc(B, Ho, Wo, K0, Ho, Wo, pc.Cout, 1, 1, 1, 0, K0, pc.Cout, 0, pc.Kpad, int(act))
-        hook = HandsLight.conv_hook
-        if hook is not None:
-            hook("begin", pc, B * Ho * Wo, stream, False)
-        check(L.hands_conv1x1_dual_nhwc_f32(C.byref(d), ptr(x), ptr(x2), K1, H2, W2, stride2, K1, ptr(pc.w), ptr(pc.bias),
-                                            ptr(out), stream), "hands_conv1x1_dual_nhwc_f32")
-        if hook is not None:
-            hook("end", pc, B * Ho * Wo, stream, False)
+    # model-less launch helpers on the default engine (tests / tools driving a single layer)
+    _conv = staticmethod(lambda *a, **kw: DEFAULT_ENGINE.conv(*a, **kw))
+    _conv_dual = staticmethod(lambda *a, **kw: DEFAULT_ENGINE.conv_dual(*a, **kw))
 
     def _trunk(self, L, P, x4, B, res_in, stream, tag, cap_B, out=None, x_off=0, out_off=0):
         """ResNet-50 trunk on an NHWC4 batch; returns (B,7,7,2048) features (flat tensor)."""
@@ -412,33 +374,30 @@ class HandsLight(nn.Module):
         a = self._buf("trunk_a_" + tag, cap, dev); b = self._buf("trunk_b_" + tag, cap, dev)
         t1 = self._buf("trunk_t1_" + tag, cap, dev); t2 = self._buf("trunk_t2_" + tag, cap, dev)
         ds = self._buf("trunk_ds_" + tag, cap, dev)
-        if HandsLight.fuse_stem_pool:
+        if self.engine.fuse_stem_pool:
             # conv1 + bn1 + relu + maxpool in one kernel: the 112x112x64 map never reaches HBM
-            pc = P["stem"]
-            Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-            check(L.hands_stem_conv_maxpool_nhwc_f32(ptr(x4, x_off), ptr(pc.w), ptr(pc.bias), ptr(b), B, H, W, 1, stream),
-                  "hands_stem_conv_maxpool_nhwc_f32")
+            Ho, Wo = self.engine.stem_pool(L, P["stem"], x4, x_off, b, B, H, W, 1, stream)
         else:
-            Ho, Wo = self._conv(L, P["stem"], x4, B, H, W, a, True, stream, x_off=x_off)
+            Ho, Wo = self.engine.conv(L, P["stem"], x4, B, H, W, a, True, stream, x_off=x_off)
             check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(b), B, Ho, Wo, 64, stream), "maxpool")
         H, W = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
         cur, nxt = b, a
         nblk = len(P["blocks"])
         for i, e in enumerate(P["blocks"]):
-            self._conv(L, e["c1"], cur, B, H, W, t1, True, stream)
-            H2, W2 = self._conv(L, e["c2"], t1, B, H, W, t2, True, stream)
+            self.engine.conv(L, e["c1"], cur, B, H, W, t1, True, stream)
+            H2, W2 = self.engine.conv(L, e["c2"], t1, B, H, W, t2, True, stream)
             last = i + 1 == nblk
             dst = nxt if not last else (out if out is not None else
                                         self._buf("feat_" + tag, B * H2 * W2 * e["c3"].Cout, dev))
-            if "ds" in e and HandsLight.fuse_downsample:
-                self._conv_dual(L, e["c3ds"], e["c3ds_split"], t2, cur, B, H2, W2, H, W, dst, stream)
+            if "ds" in e and self.engine.fuse_downsample:
+                self.engine.conv_dual(L, e["c3ds"], e["c3ds_split"], t2, cur, B, H2, W2, H, W, dst, stream)
             else:
                 if "ds" in e:
-                    self._conv(L, e["ds"], cur, B, H, W, ds, False, stream)
+                    self.engine.conv(L, e["ds"], cur, B, H, W, ds, False, stream)
                     ident = ds
                 else:
                     ident = cur
-                self._conv(L, e["c3"], t2, B, H2, W2, dst, True, stream, res=ident, out_off=out_off if last else 0)
+                self.engine.conv(L, e["c3"], t2, B, H2, W2, dst, True, stream, res=ident, out_off=out_off if last else 0)
             H, W = H2, W2
             cur, nxt = dst, cur
             if i + 1 == nblk:
@@ -476,7 +435,7 @@ class HandsLight(nn.Module):
         x4 = buf("x4", B2 * res * res * 4)
         featg = buf("feat_g", bz * 49 * F)
         feath = buf("feat_h", B2 * 49 * F)
-        gch, hch = HandsLight.trunk_chunks if HandsLight.overlap_trunks else (1, 1)
+        gch, hch = self.trunk_chunks if self.engine.overlap else (1, 1)
         gch, hch = max(1, min(gch, bz)), max(1, min(hch, B2))
         jobs = []   # (weights, images, x4 buffer, first sample, n samples, out buffer, is_global)
         for c in range(gch):
@@ -495,7 +454,7 @@ class HandsLight(nn.Module):
         done = []
         for ji, (Pt, xb, lo, n, ob, is_g) in enumerate(jobs):
             # the largest job (last) stays on the caller's stream
-            st = main if (ji == len(jobs) - 1 or not HandsLight.overlap_trunks) else self._side_stream(dev, f"side{ji}")
+            st = main if (ji == len(jobs) - 1 or not self.engine.overlap) else self._side_stream(dev, f"side{ji}")
             if st is not main:
                 st.wait_event(ev0)
             _, fh, fw = self._trunk(L, Pt, xb, n, res, st.cuda_stream, f"j{ji}", n, out=ob,
@@ -521,15 +480,15 @@ class HandsLight(nn.Module):
 
         # -- feature_conv (model.py:91-101, 313-314) -> HMR state rows ---------------------------
         f1 = buf("fc1", B2 * HW * 1024)
-        self._conv(L, P["fc0"], cat, B2, fh, fw, f1, True, stream)
+        self.engine.conv(L, P["fc0"], cat, B2, fh, fw, f1, True, stream)
         f2 = buf("fc2", B2 * (fh - 2) * (fw - 2) * 512)
-        h2, w2 = self._conv(L, P["fc2"], f1, B2, fh, fw, f2, True, stream)
+        h2, w2 = self.engine.conv(L, P["fc2"], f1, B2, fh, fw, f2, True, stream)
         f3 = buf("fc3", B2 * (h2 - 2) * (w2 - 2) * 256)
-        h3, w3 = self._conv(L, P["fc4"], f2, B2, h2, w2, f3, True, stream, splitk_n=8)   # 3x3 output map: 72 tiles at bz=256, K=4608
+        h3, w3 = self.engine.conv(L, P["fc4"], f2, B2, h2, w2, f3, True, stream, splitk_n=8)   # 3x3 output map: 72 tiles at bz=256, K=4608
         assert h3 * w3 * 256 == P["fc7"].Cin
         ld = F + HMR_VEC
         state = buf("state", B2 * ld)
-        self._conv(L, P["fc7"], f3, B2, 1, 1, state, True, stream, out_ps=ld, splitk=True)
+        self.engine.conv(L, P["fc7"], f3, B2, 1, 1, state, True, stream, out_ps=ld, splitk=True)
 
         # -- HandHMR x2 (hand_hmr.py:73-92, hmr_layer.py:67-86) ----------------------------------
         caminit4 = buf("caminit4", B2 * 4)
@@ -538,22 +497,22 @@ class HandsLight(nn.Module):
         evh.record(main)
         joins = []
         for side, hp in ((0, P["head_r"]), (1, P["head_l"])):
-            hs = main if (side == 1 or not HandsLight.overlap_trunks) else self._side_stream(dev, "side_head")
+            hs = main if (side == 1 or not self.engine.overlap) else self._side_stream(dev, "side_head")
             if hs is not main:
                 hs.wait_event(evh)
             sh = hs.cuda_stream
             h512a, h512b = buf(f"h512a{side}", bz * 512), buf(f"h512b{side}", bz * 512)
             x1, x2 = buf(f"x1024a{side}", bz * 1024), buf(f"x1024b{side}", bz * 1024)
             so = side * bz * ld
-            self._conv(L, hp["ci0"], state, bz, 1, 1, h512a, True, sh, in_ps=ld, x_off=so, splitk=True)
-            self._conv(L, hp["ci2"], h512a, bz, 1, 1, h512b, True, sh, splitk=True)
-            self._conv(L, hp["ci4"], h512b, bz, 1, 1, caminit4, False, sh, out_off=side * bz * 4)
+            self.engine.conv(L, hp["ci0"], state, bz, 1, 1, h512a, True, sh, in_ps=ld, x_off=so, splitk=True)
+            self.engine.conv(L, hp["ci2"], h512a, bz, 1, 1, h512b, True, sh, splitk=True)
+            self.engine.conv(L, hp["ci4"], h512b, bz, 1, 1, caminit4, False, sh, out_off=side * bz * 4)
             check(L.hands_hmr_init_f32(ptr(state, so), ptr(caminit4, side * bz * 4), bz, ld, F, sh),
                   "hmr_init")
             for _ in range(3):
-                self._conv(L, hp["r0"], state, bz, 1, 1, x1, True, sh, in_ps=ld, x_off=so, splitk=True)
-                self._conv(L, hp["r3"], x1, bz, 1, 1, x2, True, sh, splitk=True)
-                self._conv(L, hp["dec"], x2, bz, 1, 1, state, False, sh, res=state, out_ps=ld,
+                self.engine.conv(L, hp["r0"], state, bz, 1, 1, x1, True, sh, in_ps=ld, x_off=so, splitk=True)
+                self.engine.conv(L, hp["r3"], x1, bz, 1, 1, x2, True, sh, splitk=True)
+                self.engine.conv(L, hp["dec"], x2, bz, 1, 1, state, False, sh, res=state, out_ps=ld,
                            res_ps=ld, out_off=so + F, res_off=so + F, splitk=True)
             if hs is not main:
                 ev = torch.cuda.Event()
@@ -580,7 +539,7 @@ class HandsLight(nn.Module):
 
         # -- MANOHead x2 (mano_head.py:21-65) -----------------------------------------------------
         output = run_mano_heads(L, P["mano_r"], P["mano_l"], rot_m, shape_m, cam_m, caminit_m, K,
-                                float(self.img_res), bz, stream, buf)
+                                float(self.img_res), bz, stream, buf, self.engine)
 
         # -- grasp classifier on the UN-flipped HMR outputs (model.py:401-411) -------------------
         gld = P["g0"].Cin
@@ -589,10 +548,10 @@ class HandsLight(nn.Module):
                                       F, gld, stream), "grasp_input")
         g1, g2, g3 = buf("g1", B2 * 1024), buf("g2", B2 * 512), buf("g3", B2 * 128)
         g4 = torch.empty(B2, 12, device=dev)
-        self._conv(L, P["g0"], gin, B2, 1, 1, g1, True, stream, splitk=True)
-        self._conv(L, P["g2"], g1, B2, 1, 1, g2, True, stream, splitk=True)
-        self._conv(L, P["g4"], g2, B2, 1, 1, g3, True, stream, splitk=True)
-        self._conv(L, P["g6"], g3, B2, 1, 1, g4, False, stream)
+        self.engine.conv(L, P["g0"], gin, B2, 1, 1, g1, True, stream, splitk=True)
+        self.engine.conv(L, P["g2"], g1, B2, 1, 1, g2, True, stream, splitk=True)
+        self.engine.conv(L, P["g4"], g2, B2, 1, 1, g3, True, stream, splitk=True)
+        self.engine.conv(L, P["g6"], g3, B2, 1, 1, g4, False, stream)
         grasp = xdict()
         grasp["grasp.r"] = g4[:bz, :9].contiguous()
         grasp["grasp.l"] = g4[bz:, :9].contiguous()

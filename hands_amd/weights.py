@@ -134,6 +134,8 @@ def apply_recipe(module: torch.nn.Module) -> torch.nn.Module:
         val = recipe_tensor(key, sd[key])
         if val is not None:
             sd[key].copy_(val)
+    if hasattr(module, "invalidate_packed"):     # parameters were written in place: drop the packed copies
+        module.invalidate_packed()
     return module
 
 

@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import ManoOut, check, ptr
+from .engine import DEFAULT_ENGINE
 from .hands_light import DEFAULT_ARGS, HandsLight
 from .xdict import xdict
 
@@ -68,7 +69,7 @@ class HandsWrapper(nn.Module):
             blend_in, A, j16, vposed = new(B, 160), new(B, 192), new(B, 48), new(B, 2336)
             check(L.hands_mano_pose_aa_f32(C.byref(mp["consts"]), ptr(pose), ptr(beta), 10, ptr(blend_in), 160, ptr(A),
                                            ptr(j16), B, stream), "mano_pose_aa")
-            HandsLight._conv(L, mp["blend"], blend_in, B, 1, 1, vposed, False, stream)
+            getattr(self.model, "engine", DEFAULT_ENGINE).conv(L, mp["blend"], blend_in, B, 1, 1, vposed, False, stream)
             o = {k: new(B, n, 3) for k, n in (("vertices", 778), ("joints3d", 21), ("v3d", 778), ("j3d", 21))}
             j2d, cam_t_unused, one_cam = new(B, 21, 2), new(B, 3), torch.ones(B, 3, device=dev)
             mo = ManoOut(ptr(o["vertices"]), ptr(o["joints3d"]), ptr(o["v3d"]), ptr(o["j3d"]), ptr(j2d), ptr(cam_t_unused))

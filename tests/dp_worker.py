@@ -1,0 +1,33 @@
+"""Rank process of tests/test_gpu_dist.py (NOT a test module): one rank of a world-size-N data-parallel
+forward of the REAL HandsLight on the HIP device, every rank on cuda:0, gloo collectives on host copies
+(RCCL refuses two ranks on one GPU; the 1-GPU box cannot do better).  Rank 0 saves the gathered dict."""
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HANDS_SYNTHETIC_MANO", "1")
+
+import torch
+import torch.distributed as dist
+
+
+def main():
+    out_path, bz, seed = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import hands_amd
+    from hands_amd.dist import data_parallel_forward
+    dev = torch.device("cuda", 0)
+    model = hands_amd.apply_recipe(hands_amd.HandsLight()).to(dev).eval()
+    inputs, meta = hands_amd.synthetic_inputs(bz, seed, device=dev)        # every rank holds the GLOBAL batch
+    meta["is_flipped"] = (torch.arange(bz, device=dev) % 3 == 1).long()
+    got = data_parallel_forward(model, inputs, meta, gather_on_host=True)
+    if rank == 0:
+        torch.save({k: v.clone() for k, v in got.items()}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,10 +28,16 @@ class _FakeModel:
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    inputs, meta = hands_amd.synthetic_inputs(6, 3, img_res=8)
-    full = _FakeModel()(inputs, meta)
-    got = data_parallel_forward(_FakeModel(), inputs, meta)
-    ok = all(torch.equal(got[k], full[k]) for k in full) and list(got.keys()) == list(full.keys())
+    ok = True
+    # even shards (6), uneven shards (5: 3 + 2 rows -> padded to 3 for the collective, trimmed after),
+    # and an empty shard (1 sample on 2 ranks: rank 1 contributes zero rows)
+    for bz in (6, 5, 1):
+        inputs, meta = hands_amd.synthetic_inputs(bz, 3, img_res=8)
+        meta["imgname"] = [f"{i}.jpg" for i in range(bz)]
+        full = _FakeModel()(inputs, meta)
+        got = data_parallel_forward(_FakeModel(), inputs, meta)
+        ok = ok and all(torch.equal(got[k], full[k]) for k in full) and list(got.keys()) == list(full.keys())
+        ok = ok and all(got[k].shape[0] == bz for k in got)
     single = gather_predictions({"x": torch.full((2, 3), float(rank))})
     ok = ok and torch.equal(single["x"], torch.tensor([[0.0] * 3] * 2 + [[1.0] * 3] * 2))
     q.put((rank, bool(ok)))

@@ -1,0 +1,66 @@
+"""Multi-rank runs of the REAL HIP path on the one GPU of the test box."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import hands_amd
+from hands_amd.weights import synthetic_inputs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("bz", [5, 4])
+def test_two_ranks_of_the_real_model_equal_the_single_process_forward(tmp_path, recipe_model, bz):
+    """Two rank processes (started fresh, each on cuda:0) shard a global batch -- bz=5 is UNEVEN (3 + 2
+    samples) --, run hands_amd.HandsLight on their shard and all-gather the packed predictions; the gathered
+    dict must equal the single-process forward of the global batch BIT FOR BIT (samples are independent and
+    every kernel's summation order is batch-size invariant)."""
+    out_path = str(tmp_path / "gathered.pt")
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HANDS_SYNTHETIC_MANO="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out_path, str(bz), "11"],
+                                      env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = torch.load(out_path)
+    import copy
+    model = copy.deepcopy(recipe_model).to("cuda")
+    inputs, meta = synthetic_inputs(bz, 11, device="cuda")
+    meta["is_flipped"] = (torch.arange(bz, device="cuda") % 3 == 1).long()
+    ref = model(inputs, meta)
+    torch.cuda.synchronize()
+    assert list(got.keys()) == list(ref.keys()) and len(got) == 22
+    for k in ref:
+        assert got[k].shape == ref[k].shape and torch.equal(got[k], ref[k].cpu()), k
+
+
+def test_bench_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must start 2 rank processes itself (the driver calls it
+    that way) and print ONE line with n_gpus = 2.  Dry run of that path on the 1-GPU box: both ranks share
+    cuda:0 and gather through gloo (HANDS_BENCH_SHARE_GPU / HANDS_BENCH_BACKEND; never set by the driver)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(HANDS_BENCH_SHARE_GPU="1", HANDS_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--bz", "8", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["global_batch"] == 16
+    assert d["config"]["launched_by"] == "bench.py launcher" and d["value"] > 0
+    assert d["roofline"]["kernel_ms_per_step"] <= d["roofline"]["step_ms_same_mode"]

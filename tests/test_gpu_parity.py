@@ -16,6 +16,7 @@ import torch.nn.functional as F
 import hands_amd
 from hands_amd import _lib
 from hands_amd._lib import check, ptr
+from hands_amd.engine import DEFAULT_ENGINE, ConvEngine
 from hands_amd.hands_light import HandsLight
 from hands_amd.mano import synthetic_mano_asset
 from hands_amd.packing import fold_bn, pack_conv, pack_linear, pack_mano
@@ -34,7 +35,7 @@ def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
 
-def _run_conv(x_nchw, w, bias, stride, pad, relu, res_nchw=None, cin_pad_to=None):
+def _run_conv(x_nchw, w, bias, stride, pad, relu, res_nchw=None, cin_pad_to=None, engine=None):
     L = _lib.lib()
     B, Cin, H, W = x_nchw.shape
     pc = pack_conv(w, bias, stride, pad, DEV, cin_pad_to=cin_pad_to)
@@ -46,7 +47,7 @@ def _run_conv(x_nchw, w, bias, stride, pad, relu, res_nchw=None, cin_pad_to=None
     Wo = (W + 2 * pad - w.shape[3]) // stride + 1
     out = torch.full((B, Ho, Wo, pc.Cout), float("nan"), device=DEV)
     res = _nhwc(res_nchw).to(DEV) if res_nchw is not None else None
-    HandsLight._conv(L, pc, x, B, H, W, out, relu, _stream(), res=res)
+    (engine or DEFAULT_ENGINE).conv(L, pc, x, B, H, W, out, relu, _stream(), res=res)
     torch.cuda.synchronize()
     return out.cpu().permute(0, 3, 1, 2)[:, : w.shape[0]]
 
@@ -124,12 +125,11 @@ def test_conv_igemm_latency_mode_split_k(case):
         ref = ref + res.double()
     if relu:
         ref = F.relu(ref)
-    HandsLight.latency_mode = True
-    try:
-        got = _run_conv(x, w, bias, stride, pad, relu, res)
-        again = _run_conv(x, w, bias, stride, pad, relu, res)
-    finally:
-        HandsLight.latency_mode = False
+    eng = ConvEngine()
+    eng.latency_mode = True
+    got = _run_conv(x, w, bias, stride, pad, relu, res, engine=eng)
+    again = _run_conv(x, w, bias, stride, pad, relu, res, engine=eng)
+    assert not DEFAULT_ENGINE.latency_mode                        # per-engine state, nothing global was touched
     assert torch.equal(got, again)                                 # deterministic
     err = (got.double() - ref).abs().max().item()
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
@@ -430,12 +430,12 @@ def test_forward_latency_mode_vs_golden(golden_dir, gpu_model, seed):
     d = np.load(os.path.join(golden_dir, f"hands_light_bz2_seed{seed}.npz"))
     inputs, meta_info = synthetic_inputs(2, seed, device=DEV)
     meta_info["is_flipped"] = torch.from_numpy(d["is_flipped"]).to(DEV)
-    HandsLight.latency_mode = True
+    gpu_model.latency_mode = True
     try:
         out = gpu_model(inputs, meta_info)
         torch.cuda.synchronize()
     finally:
-        HandsLight.latency_mode = False
+        gpu_model.latency_mode = False
     for hn in "rl":
         verr = np.abs(out[f"mano.vertices.{hn}"].cpu().numpy() - d[f"out/mano.vertices.{hn}"]).max()
         assert verr < 1e-6, verr
@@ -467,7 +467,7 @@ def test_replica_on_a_second_stream(gpu_model):
     inputs, meta_info = synthetic_inputs(4, 3, device=DEV)
     ref = {k: v.clone() for k, v in gpu_model(inputs, meta_info).items()}
     rep = gpu_model.replica()
-    assert rep._packed is gpu_model._packed and rep._ws is not gpu_model._ws
+    assert rep._packed is gpu_model._packed and rep._ws is not gpu_model._ws and rep.engine is not gpu_model.engine
     s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
     outs = []

@@ -7,7 +7,7 @@ dev = torch.device("cuda:0")
 m = hands_amd.apply_recipe(hands_amd.HandsLight()).to(dev).eval()
 import numpy as np
 for mode in (False, True):
-  hands_amd.HandsLight.latency_mode = mode
+  m.latency_mode = mode
   print("latency_mode", mode)
   for bz in (1, 2, 8, 32):
       inputs, meta = synthetic_inputs(bz, seed=0)
