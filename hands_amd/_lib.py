@@ -33,6 +33,10 @@ class ManoOut(C.Structure):
                 ("j3d_cam", C.c_void_p), ("j2d_norm", C.c_void_p), ("cam_t", C.c_void_p)]
 
 
+class PackedDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("Cin", "Cout", "Cout_pad", "Kpad")]
+
+
 class EvalIn(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "pred_j3d_r", "pred_j3d_l", "gt_j3d_r", "gt_j3d_l", "pred_j2d_r", "pred_j2d_l", "gt_j2d_r", "gt_j2d_l",
@@ -89,8 +93,15 @@ SIGNATURES = {
     "hands_unnormalize_kp2d_f32": [_P, _P, C.c_longlong, _F, _P],
     "hands_frontend_boxes_f32": [_P, _P, _I, _P, _I, _I, _I, C.c_double] + [_P] * 10 + [_P],
     "hands_warp_affine_cubic_norm_f32": [_P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P],
+    # host-side packing (csrc/pack.cpp): HOST pointers
+    "hands_pack_conv_dims": [_I, _I, _I, _I, _I, C.POINTER(PackedDims)],
+    "hands_fold_bn_f32": [_I, C.c_longlong, _P, _P, _P, _P, _P, C.c_double, _P, _P],
+    "hands_pack_conv_f64": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "hands_pack_linear_f64": [_I, _I, _P, _P, _P, _I, _P, _I, _P, _P],
+    "hands_pack_conv1x1_dual_f64": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "hands_pack_mano_f32": [_P] * 10,
 }
-EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string")
+EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string", "hands_conv2d_workspace_floats")
 
 _lib = None
 
@@ -109,6 +120,8 @@ def lib():
         fn = getattr(h, name)
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    h.hands_conv2d_workspace_floats.restype = C.c_longlong
+    h.hands_conv2d_workspace_floats.argtypes = [C.POINTER(ConvDesc), C.c_int]
     h.hands_abi_version.restype = C.c_int
     h.hands_error_string.restype = C.c_char_p
     h.hands_error_string.argtypes = [C.c_int]

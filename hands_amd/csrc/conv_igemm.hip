@@ -371,6 +371,14 @@ bool pointwise_route_ok(const hands_conv_desc* d) {
 
 extern "C" int hands_conv2d_splitk_factor(const hands_conv_desc* d) { return d ? splitk_factor(d) : 0; }
 
+extern "C" long long hands_conv2d_workspace_floats(const hands_conv_desc* d, int S) {
+  if (!d || !conv_geometry_ok(d)) return -1;
+  if (S <= 0) S = splitk_factor(d);
+  if (S > d->Kpad / BK) S = d->Kpad / BK;
+  if (S <= 1) return 0;
+  return (long long)S * d->B * d->Ho * d->Wo * d->Cout;
+}
+
 extern "C" int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
                                      const float* bias, const float* residual, float* out,
                                      hands_stream_t stream) {

@@ -72,7 +72,7 @@ class ConvEngine:
             tiles = -(-(B * Ho * Wo) // bm) * -(-pc.Cout // bn)
             S = max(S, min(256 // tiles, pc.Kpad // 128, 32)) if tiles <= 128 else S
         if S > 1:     # latency-bound GEMM: deterministic split-K with a per-stream workspace
-            ws = self._workspace(x.device, stream, S * B * Ho * Wo * pc.Cout)
+            ws = self._workspace(x.device, stream, L.hands_conv2d_workspace_floats(C.byref(d), S))
             check(L.hands_conv2d_nhwc_splitk_n_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
                                                    ptr(res, res_off) if res is not None else None, ptr(out, out_off),
                                                    S, ptr(ws), ws.numel(), stream), "hands_conv2d_nhwc_splitk_n_f32")

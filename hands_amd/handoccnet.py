@@ -26,7 +26,7 @@ from . import _lib
 from ._lib import ACT_GELU, ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, check, ptr
 from .engine import ConvEngine, EngineSwitches
 from .hands_light import MANOHead, _Args, mano_consts, run_mano_heads
-from .packing import BN_EPS, PackedConv, pack_conv, pack_linear, pack_mano
+from .packing import BN_EPS, PackedConv, fold_bn, pack_conv, pack_linear, pack_mano
 from .param_tree import build_tree, load_manifest
 from .xdict import xdict
 
@@ -107,8 +107,10 @@ class HandOccNet(EngineSwitches, nn.Module):
         sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
 
         def bn_affine(p, eps=BN_EPS):
-            s = sd[p + ".weight"].double() / torch.sqrt(sd[p + ".running_var"].double() + eps)
-            return s, sd[p + ".bias"].double() - sd[p + ".running_mean"].double() * s
+            # scale / shift of an eval BatchNorm through the library's fp64 fold (w = 1 -> w_folded = scale)
+            ones = torch.ones(sd[p + ".weight"].shape[0], 1, 1, 1)
+            s, t = fold_bn(ones, sd[p + ".weight"], sd[p + ".bias"], sd[p + ".running_mean"], sd[p + ".running_var"], eps)
+            return s.view(-1), t
 
         def conv(p, stride=1, pad=0, bn=None, cin_pad_to=None):
             """conv (+ optional bias) followed by an optional eval-BatchNorm, folded."""

@@ -31,8 +31,8 @@ from . import _lib
 from ._lib import ManoConsts, ManoOut, check, ptr
 from .engine import DEFAULT_ENGINE, ConvEngine, EngineSwitches
 from .mano import ManoLayer, build_mano_asset
-from .packing import (HMR_VEC, PackedConv, fold_bn, hmr_state_columns, pack_conv, pack_linear,
-                      pack_mano)
+from .packing import (HMR_VEC, PackedConv, fold_bn, hmr_state_columns, pack_conv, pack_conv1x1_dual,
+                      pack_linear, pack_mano)
 from .xdict import prefix_dict, xdict
 
 RESNET50_LAYERS = (3, 4, 6, 3)
@@ -271,7 +271,7 @@ class HandsLight(EngineSwitches, nn.Module):
                     e["ds"] = pack_conv(w, b, blk.stride, 0, dev)
                     # conv3 + downsample as ONE GEMM over K = planes + inplanes (hands_conv1x1_dual_nhwc_f32)
                     w3, b3 = fold_bn(cpu(blk.conv3.weight), *bnp(blk.bn3))
-                    e["c3ds"] = pack_conv(torch.cat([w3.double(), w.double()], 1), b3.double() + b.double(), 1, 0, dev)
+                    e["c3ds"] = pack_conv1x1_dual(w3, b3, w, b, dev)
                     e["c3ds_split"] = (w3.shape[1], w.shape[1], blk.stride)
                 blocks.append(e)
         P["blocks"] = blocks

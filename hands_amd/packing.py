@@ -1,27 +1,28 @@
 """One-time host-side packing of reference-layout parameters into the layouts the HIP kernels read.
 
+Thin ctypes wrapper over the HOST entry points of libhands_hip.so (``hands_pack_*``, csrc/pack.cpp,
+declared in include/hands_hip.h): a non-Python host packs a reference checkpoint with the same calls.
 Not on the hot path: runs once per ``load_state_dict`` / device move.
 
 * conv + eval BatchNorm2d -> folded weight/bias (reference applies them separately:
-  src/nets/backbone/resnet.py:137-149);
+  src/nets/backbone/resnet.py:137-149), fp64 fold, one rounding to fp32;
 * weights to ``[Cout_pad][Kpad]`` with k ordered (kh, kw, cin) -- see include/hands_hip.h;
 * column permutations that keep every operand segment 16-byte aligned (HMR state row, grasp row,
   NCHW ``nn.Flatten`` order of feature_conv's Linear).
 """
 from __future__ import annotations
 
+import ctypes as C
 from dataclasses import dataclass
 
 import numpy as np
 import torch
 
+from . import _lib
+from ._lib import PackedDims, check
 from .mano import ManoAsset, TIP_IDS
 
 BN_EPS = 1e-5
-
-
-def _round_up(x, m):
-    return (x + m - 1) // m * m
 
 
 @dataclass
@@ -38,53 +39,81 @@ class PackedConv:
     macs_per_pixel: int = 0   # ALGORITHMIC multiply-accumulates per output pixel (true, unpadded dims)
 
 
+def _f64(t):
+    """contiguous float64 numpy view of a CPU tensor / array (None stays None)."""
+    if t is None:
+        return None
+    a = t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _f32(t):
+    a = t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
 def fold_bn(w, bn_w, bn_b, bn_mean, bn_var, eps=BN_EPS):
-    """(Cout,Cin,KH,KW) conv weight + BN stats -> folded weight, bias (fp64 math, fp32 result)."""
-    scale = bn_w.double() / torch.sqrt(bn_var.double() + eps)
-    wf = w.double() * scale.view(-1, 1, 1, 1)
-    bf = bn_b.double() - bn_mean.double() * scale
-    return wf, bf
+    """(Cout,Cin,KH,KW) conv weight + BN stats -> folded weight, bias (fp64 tensors; hands_fold_bn_f32)."""
+    wn = _f32(w)
+    Cout = wn.shape[0]
+    per = int(wn.size // Cout)
+    wf = np.empty(wn.shape, np.float64)
+    bf = np.empty(Cout, np.float64)
+    g, b, m, v = (_f32(t) for t in (bn_w, bn_b, bn_mean, bn_var))
+    check(_lib.lib().hands_fold_bn_f32(Cout, per, _p(wn), _p(g), _p(b), _p(m), _p(v), float(eps), _p(wf), _p(bf)),
+          "hands_fold_bn_f32")
+    return torch.from_numpy(wf), torch.from_numpy(bf)
 
 
 def pack_conv(w, bias, stride, pad, device, cin_pad_to=None) -> PackedConv:
-    """w: (Cout, Cin, KH, KW) (any float dtype, CPU); bias: (Cout,) or None."""
+    """w: (Cout, Cin, KH, KW) (any float dtype, CPU); bias: (Cout,) or None.  hands_pack_conv_f64."""
+    L = _lib.lib()
     Cout, Cin, KH, KW = w.shape
-    Cin_p = cin_pad_to or Cin
-    wk = torch.zeros(Cout, KH, KW, Cin_p, dtype=torch.float64)
-    wk[..., :Cin] = w.double().permute(0, 2, 3, 1)
-    K = KH * KW * Cin_p
-    Kpad = _round_up(K, 16)
-    Cout_s = _round_up(Cout, 4)
-    Cout_pad = _round_up(Cout, 128)
-    wp = torch.zeros(Cout_pad, Kpad, dtype=torch.float32)
-    wp[:Cout, :K] = wk.reshape(Cout, K).float()
-    bp = torch.zeros(Cout_pad, dtype=torch.float32)
-    if bias is not None:
-        bp[:Cout] = bias.float()
-    return PackedConv(wp.to(device), bp.to(device), Cin_p, Cout_s, KH, KW, stride, pad, Kpad,
-                      macs_per_pixel=Cout * Cin * KH * KW)
+    d = PackedDims()
+    check(L.hands_pack_conv_dims(Cout, Cin, KH, KW, int(cin_pad_to or 0), C.byref(d)), "hands_pack_conv_dims")
+    wn, bn = _f64(w), _f64(bias)
+    wp = np.empty((d.Cout_pad, d.Kpad), np.float32)
+    bp = np.empty(d.Cout_pad, np.float32)
+    check(L.hands_pack_conv_f64(Cout, Cin, KH, KW, int(cin_pad_to or 0), _p(wn), _p(bn), _p(wp), _p(bp)),
+          "hands_pack_conv_f64")
+    return PackedConv(torch.from_numpy(wp).to(device), torch.from_numpy(bp).to(device), d.Cin, d.Cout, KH, KW,
+                      stride, pad, d.Kpad, macs_per_pixel=Cout * Cin * KH * KW)
+
+
+def pack_conv1x1_dual(w0, b0, w1, b1, device) -> PackedConv:
+    """conv3 + downsample of a stage's first bottleneck as one two-source GEMM: inputs are the fp64 folds
+    (Cout,K0,1,1), (Cout,K1,1,1) and their biases.  hands_pack_conv1x1_dual_f64."""
+    Cout, K0, K1 = w0.shape[0], w0.shape[1], w1.shape[1]
+    Kpad, Cout_pad = (K0 + K1 + 15) // 16 * 16, (Cout + 127) // 128 * 128
+    wp = np.empty((Cout_pad, Kpad), np.float32)
+    bp = np.empty(Cout_pad, np.float32)
+    a0, c0, a1, c1 = _f64(w0).reshape(Cout, K0), _f64(b0), _f64(w1).reshape(Cout, K1), _f64(b1)
+    check(_lib.lib().hands_pack_conv1x1_dual_f64(Cout, K0, K1, _p(a0), _p(c0), _p(a1), _p(c1), _p(wp), _p(bp)),
+          "hands_pack_conv1x1_dual_f64")
+    return PackedConv(torch.from_numpy(wp).to(device), torch.from_numpy(bp).to(device), K0 + K1, (Cout + 3) // 4 * 4, 1, 1,
+                      1, 0, Kpad, macs_per_pixel=Cout * (K0 + K1))
 
 
 def pack_linear(w, bias, device, col_index=None, k_total=None, row_index=None, n_total=None) -> PackedConv:
     """nn.Linear weight (N, K) -> 1x1 'conv'.  ``col_index[k_ref] = k_packed`` places reference input
     column k_ref at packed column k_packed (row of width ``k_total``); ``row_index`` likewise for
-    output rows (``n_total`` stored outputs)."""
+    output rows (``n_total`` stored outputs).  hands_pack_linear_f64."""
     N, K = w.shape
-    kt = k_total or K
-    nt = n_total or N
-    w2 = torch.zeros(nt, kt, dtype=torch.float64)
-    ci = torch.arange(K) if col_index is None else torch.as_tensor(col_index)
-    ri = torch.arange(N) if row_index is None else torch.as_tensor(row_index)
-    tmp = torch.zeros(N, kt, dtype=torch.float64)
-    tmp[:, ci] = w.double()
-    w2[ri] = tmp
-    b2 = torch.zeros(nt, dtype=torch.float64)
-    if bias is not None:
-        b2[ri] = bias.double()
-    kp = _round_up(kt, 16)
-    pc = pack_conv(w2.view(nt, kt, 1, 1), b2, 1, 0, device, cin_pad_to=kp)
-    pc.macs_per_pixel = N * K
-    return pc
+    kt, nt = int(k_total or K), int(n_total or N)
+    Kpad, Cout_pad = (kt + 15) // 16 * 16, (nt + 127) // 128 * 128
+    wp = np.empty((Cout_pad, Kpad), np.float32)
+    bp = np.empty(Cout_pad, np.float32)
+    ci = None if col_index is None else np.ascontiguousarray(np.asarray(col_index), dtype=np.int32)
+    ri = None if row_index is None else np.ascontiguousarray(np.asarray(row_index), dtype=np.int32)
+    wn, bn = _f64(w), _f64(bias)
+    check(_lib.lib().hands_pack_linear_f64(N, K, _p(wn), _p(bn), _p(ci), kt, _p(ri), nt, _p(wp), _p(bp)),
+          "hands_pack_linear_f64")
+    return PackedConv(torch.from_numpy(wp).to(device), torch.from_numpy(bp).to(device), Kpad, (nt + 3) // 4 * 4, 1, 1, 1, 0,
+                      Kpad, macs_per_pixel=N * K)
 
 
 # HMR state row layout (see hands_hmr_init_f32): feat | pose6d 96 | shape 10 | 2 pad | cam 3 | 1 pad
@@ -100,17 +129,15 @@ HMR_VEC = 112  # width of the vector part of the state row
 
 
 def pack_mano(asset: ManoAsset, device):
-    """MANO constants for the pose / blend-GEMM / skin kernels."""
-    vt = asset.v_template.astype(np.float64)
-    sd = asset.shapedirs.astype(np.float64)              # (778,3,10)
-    Jr = asset.J_regressor.astype(np.float64)            # (16,778)
-    J_template = (Jr @ vt).astype(np.float32)            # (16,3)
-    J_shapedirs = np.einsum("jv,vck->jck", Jr, sd).reshape(48, 10).astype(np.float32)
-    pose_mean = np.concatenate([np.zeros(3, np.float32), asset.hands_mean.astype(np.float32)])
-    # blend matrix as a Linear weight (N=2334 outputs, K=145 inputs [beta | pose_feature])
-    Wb = np.concatenate([sd.reshape(-1, 10), asset.posedirs.astype(np.float64).T], axis=1)  # (2334,145)
-    blend = pack_linear(torch.from_numpy(Wb), torch.from_numpy(vt.reshape(-1)), device,
-                        k_total=145, n_total=2336)
+    """MANO constants for the pose / blend-GEMM / skin kernels.  hands_pack_mano_f32."""
+    vt, sd, pd, Jr, hm = (_f32(a) for a in (asset.v_template, asset.shapedirs, asset.posedirs, asset.J_regressor,
+                                            asset.hands_mean))
+    pose_mean, J_template, J_shapedirs = np.empty(48, np.float32), np.empty((16, 3), np.float32), np.empty((48, 10), np.float32)
+    bw, bb = np.empty((2432, 160), np.float32), np.empty(2432, np.float32)
+    check(_lib.lib().hands_pack_mano_f32(_p(vt), _p(sd), _p(pd), _p(Jr), _p(hm), _p(pose_mean), _p(J_template),
+                                         _p(J_shapedirs), _p(bw), _p(bb)), "hands_pack_mano_f32")
+    blend = PackedConv(torch.from_numpy(bw).to(device), torch.from_numpy(bb).to(device), 160, 2336, 1, 1, 1, 0, 160,
+                       macs_per_pixel=2334 * 145)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     return {
         "pose_mean": t(pose_mean), "J_template": t(J_template), "J_shapedirs": t(J_shapedirs),

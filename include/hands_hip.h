@@ -359,6 +359,45 @@ int hands_warp_affine_cubic_norm_f32(const float* src, const float* trans, float
                                      int Ho, int Wo, const float* mean3, const float* std3,
                                      hands_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * One-time HOST-side packing (csrc/pack.cpp): reference-layout parameters -> the layouts above.
+ * Host pointers only, no GPU call, no allocation kept.  A host in any language packs a reference
+ * checkpoint with these and uploads the results; hands_amd/packing.py is a thin ctypes wrapper.
+ *   hands_pack_conv_dims   sizes of the packed buffers for a (Cout, Cin, KH, KW) convolution whose input
+ *                          channels are padded to cin_pad_to (0 = Cin; 4 for the RGB0 stem).
+ *   hands_fold_bn_f32      eval-mode BatchNorm2d folded into the preceding conv, in fp64
+ *                          (resnet.py:137-149 applies them separately): per_out = Cin*KH*KW.
+ *   hands_pack_conv_f64    (Cout,Cin,KH,KW) fp64 -> w_packed [Cout_pad][Kpad] fp32, bias [Cout_pad] (NULL = 0).
+ *   hands_pack_linear_f64  nn.Linear (N,K) as a 1x1 conv with optional input-column / output-row
+ *                          permutations (the HMR state row, the grasp row, the NCHW nn.Flatten order).
+ *   hands_pack_conv1x1_dual_f64  weight of hands_conv1x1_dual_nhwc_f32: [W0 | W1], bias b0 + b1.
+ *   hands_pack_mano_f32    MANO constants (hands_mano_consts members + the blend GEMM weight/bias).
+ * hands_conv2d_workspace_floats: floats of split-K workspace hands_conv2d_nhwc_splitk_n_f32 needs for
+ *   S slices (S <= 0: the library's own hands_conv2d_splitk_factor); 0 when no split is taken.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct hands_packed_dims {
+  int32_t Cin;       /* channels the kernel sees (padded) = desc.Cin */
+  int32_t Cout;      /* channels the kernel stores = round_up(Cout, 4) = desc.Cout */
+  int32_t Cout_pad;  /* rows of w_packed / entries of bias = round_up(Cout, 128) */
+  int32_t Kpad;      /* row length of w_packed = round_up(KH*KW*Cin, 16) = desc.Kpad */
+} hands_packed_dims;
+
+int hands_pack_conv_dims(int Cout, int Cin, int KH, int KW, int cin_pad_to, hands_packed_dims* dims);
+int hands_fold_bn_f32(int Cout, long long per_out, const float* w, const float* gamma, const float* beta,
+                      const float* mean, const float* var, double eps, double* w_folded, double* bias_folded);
+int hands_pack_conv_f64(int Cout, int Cin, int KH, int KW, int cin_pad_to, const double* w_oihw,
+                        const double* bias, float* w_packed, float* bias_packed);
+int hands_pack_linear_f64(int N, int K, const double* w, const double* bias, const int32_t* col_index,
+                          int k_total, const int32_t* row_index, int n_total, float* w_packed,
+                          float* bias_packed);
+int hands_pack_conv1x1_dual_f64(int Cout, int K0, int K1, const double* w0, const double* b0,
+                                const double* w1, const double* b1, float* w_packed, float* bias_packed);
+int hands_pack_mano_f32(const float* v_template, const float* shapedirs, const float* posedirs,
+                        const float* J_regressor, const float* hands_mean, float* pose_mean,
+                        float* J_template, float* J_shapedirs, float* blend_w_packed,
+                        float* blend_bias_packed);
+long long hands_conv2d_workspace_floats(const hands_conv_desc* d, int S);
+
 #ifdef __cplusplus
 }
 #endif

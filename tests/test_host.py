@@ -121,6 +121,7 @@ def test_pack_mano_blend_matrix_reproduces_blendshapes():
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "hands_hip.h")).read()
     declared = set(re.findall(r"^(?:int|const char\*)\s+(hands_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    declared |= set(re.findall(r"^long long\s+(hands_[a-z0-9_]+)\s*\(", header, flags=re.M))
     declared -= {"hands_conv_desc", "hands_mano_consts", "hands_mano_out"}
     assert declared == set(_lib.SIGNATURES) | set(_lib.EXTRA_SYMBOLS), declared ^ (set(_lib.SIGNATURES) | set(_lib.EXTRA_SYMBOLS))
     L = _lib.lib()                                   # loads without a GPU
@@ -129,6 +130,61 @@ def test_library_exports_every_declared_symbol():
     assert L.hands_abi_version() == 1
     assert L.hands_error_string(0) == b"ok" and b"invalid" in L.hands_error_string(10001)
     assert ctypes.sizeof(_lib.ConvDesc) == 16 * 4
+
+
+def test_c_packers_equal_the_python_restatement_bit_for_bit():
+    """`hands_pack_*` live behind the C ABI (csrc/pack.cpp, host code); hands_amd.packing is a
+    ctypes wrapper.  tests/ref_packing.py is an independent pure-torch restatement of the layouts: every
+    packed weight / bias must be equal bit for bit."""
+    import ref_packing as R
+    from hands_amd.packing import pack_conv1x1_dual
+    g = torch.Generator().manual_seed(4)
+    eq = lambda a, b: (torch.equal(a.w, b.w) and torch.equal(a.bias, b.bias) and
+                       (a.Cin, a.Cout, a.KH, a.KW, a.stride, a.pad, a.Kpad, a.macs_per_pixel) ==
+                       (b.Cin, b.Cout, b.KH, b.KW, b.stride, b.pad, b.Kpad, b.macs_per_pixel))
+    for (Cout, Cin, k, cin_pad) in ((24, 16, 3, None), (64, 3, 7, 4), (130, 32, 1, None), (256, 64, 1, None)):
+        w = torch.randn(Cout, Cin, k, k, generator=g)
+        bn = [torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g), torch.randn(Cout, generator=g),
+              torch.rand(Cout, generator=g) + 0.5]
+        wf, bf = fold_bn(w, *bn)
+        wr, br = R.fold_bn(w, *bn)
+        assert wf.dtype == torch.float64 and torch.equal(wf, wr) and torch.equal(bf, br)
+        assert eq(pack_conv(wf, bf, 2, 1, "cpu", cin_pad_to=cin_pad), R.pack_conv(wr, br, 2, 1, "cpu", cin_pad_to=cin_pad))
+        assert eq(pack_conv(w, None, 1, 0, "cpu", cin_pad_to=cin_pad), R.pack_conv(w, None, 1, 0, "cpu", cin_pad_to=cin_pad))
+    # linear layers with column / row permutations (HMR state row, decoder stack)
+    F_ = 48
+    w, b = torch.randn(40, F_ + 109, generator=g), torch.randn(40, generator=g)
+    cols = hmr_state_columns(F_)
+    assert eq(pack_linear(w, b, "cpu", col_index=cols, k_total=F_ + 112), R.pack_linear(w, b, "cpu", col_index=cols, k_total=F_ + 112))
+    rows = list(range(96)) + [96 + i for i in range(10)] + [108 + i for i in range(3)]
+    wd = torch.randn(109, 32, generator=g)
+    assert eq(pack_linear(wd, None, "cpu", row_index=rows, n_total=112), R.pack_linear(wd, None, "cpu", row_index=rows, n_total=112))
+    assert eq(pack_linear(w, b, "cpu", n_total=44), R.pack_linear(w, b, "cpu", n_total=44))
+    # two-source 1x1 (conv3 + downsample): [W0 | W1], bias summed in fp64
+    w0, w1 = torch.randn(256, 64, 1, 1, generator=g).double(), torch.randn(256, 128, 1, 1, generator=g).double()
+    b0, b1 = torch.randn(256, generator=g).double(), torch.randn(256, generator=g).double()
+    assert eq(pack_conv1x1_dual(w0, b0, w1, b1, "cpu"), R.pack_conv(torch.cat([w0, w1], 1), b0 + b1, 1, 0, "cpu"))
+    # MANO constants: blend matrix bit-exact; the J_regressor contractions are fp64 sums of 778 terms whose
+    # order differs from numpy's dgemm -> equal up to one fp32 rounding
+    a = hands_amd.synthetic_mano_asset(False)
+    m, r = pack_mano(a, "cpu"), R.pack_mano(a, "cpu")
+    assert eq(m["blend"], r["blend"])
+    for k in ("pose_mean", "lbs_weights", "tip_ids", "faces"):
+        assert torch.equal(m[k], r[k]), k
+    for k in ("J_template", "J_shapedirs"):
+        assert m[k].shape == r[k].shape and (m[k] - r[k]).abs().max() <= 2 ** -23 * r[k].abs().max(), k
+
+
+def test_workspace_query_matches_the_split_policy():
+    L = _lib.lib()
+    d = _lib.ConvDesc(256, 1, 1, 2304, 1, 1, 2048, 1, 1, 1, 0, 2304, 2048, 0, 2304, 1)    # feature_conv Linear at bz=128
+    S = L.hands_conv2d_splitk_factor(ctypes.byref(d))
+    assert S == 8 and L.hands_conv2d_workspace_floats(ctypes.byref(d), 0) == 8 * 256 * 2048
+    assert L.hands_conv2d_workspace_floats(ctypes.byref(d), 3) == 3 * 256 * 2048
+    assert L.hands_conv2d_workspace_floats(ctypes.byref(d), 1) == 0
+    d2 = _lib.ConvDesc(4, 56, 56, 64, 56, 56, 64, 3, 3, 1, 1, 64, 64, 0, 576, 1)           # a trunk conv: never split by policy
+    assert L.hands_conv2d_workspace_floats(ctypes.byref(d2), 0) == 0
+    assert L.hands_conv2d_workspace_floats(None, 2) == -1
 
 
 def test_bad_descriptors_are_rejected_without_a_gpu():
