@@ -33,6 +33,11 @@ class ManoOut(C.Structure):
                 ("j3d_cam", C.c_void_p), ("j2d_norm", C.c_void_p), ("cam_t", C.c_void_p)]
 
 
+class ManoSide(C.Structure):
+    _fields_ = [("consts", ManoConsts), ("blend_w", C.c_void_p), ("blend_bias", C.c_void_p), ("rot", C.c_void_p),
+                ("betas", C.c_void_p), ("cam_wp", C.c_void_p), ("out", ManoOut)]
+
+
 class PackedDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("Cin", "Cout", "Cout_pad", "Kpad")]
 
@@ -68,6 +73,7 @@ SIGNATURES = {
     "hands_axis_angle_to_matrix_f32": [_P, _P, C.c_longlong, _P],
     "hands_grasp_input_f32": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "hands_mano_pose_f32": [C.POINTER(ManoConsts), _P, _P, _I, _P, _I, _P, _P, _I, _P],
+    "hands_mano_heads_f32": [C.POINTER(ManoSide), _I, _P, _I, _F, _F, _I, _I, _P],
     "hands_mano_skin_f32": [C.POINTER(ManoConsts), _P, _I, _P, _P, _P, _P, _F, _F, C.POINTER(ManoOut), _I, _P],
     "hands_resize_crop_nchw3_to_nhwc4_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hands_layernorm_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P],

@@ -353,8 +353,10 @@ bool conv_geometry_ok(const hands_conv_desc* d) {
   if (d->Cin % 4 || d->Cout % 4 || d->Kpad % BK || d->Kpad < d->KH * d->KW * d->Cin) return false;
   if (d->Cin != 4 && d->Cin % 16) return false;
   if (d->in_pix_stride < d->Cin || d->out_pix_stride < d->Cout) return false;
-  // last output pixel's window must start inside the padded input
-  if ((long long)(d->Ho - 1) * d->stride - d->pad >= d->H || (long long)(d->Wo - 1) * d->stride - d->pad >= d->W) return false;
+  // the output map may not be larger than the one the geometry produces (the padded-convolution k-loop
+  // checks every tap against the image; a larger map would still index pixels of the next image / past the end)
+  if (d->H + 2 * d->pad < d->KH || d->W + 2 * d->pad < d->KW) return false;
+  if (d->Ho > (d->H + 2 * d->pad - d->KH) / d->stride + 1 || d->Wo > (d->W + 2 * d->pad - d->KW) / d->stride + 1) return false;
   if ((long long)d->B * d->H * d->W * d->in_pix_stride >= (1LL << 31)) return false;
   if ((long long)d->B * d->Ho * d->Wo >= (1LL << 31) / (d->out_pix_stride > 0 ? d->out_pix_stride : 1)) return false;
   return true;

@@ -195,9 +195,334 @@ __global__ void __launch_bounds__(256) mano_skin_kernel(hands_mano_consts c, con
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// mano_heads_kernel: MANOHead.forward for BOTH hands in ONE launch (BASELINE configs[4]: the 6 launches of
+// pose -> blend GEMM -> skin per side become 1).  A block owns 16 hands of one side and a range of 64-vertex
+// chunks:
+//   phase 1  one thread per (hand, joint): R -> axis-angle -> (+pose_mean) -> Rodrigues, J(beta), forward
+//            kinematics, skinning transforms A -- exactly mano_pose_kernel's arithmetic -- into LDS, with the
+//            blend-GEMM input rows [beta | R - I | 0] (16 x 160);
+//   phase 2  per chunk: v_posed[192 x 16 hands] = Wb[192 x 160] . blend_in^T + v_template on the fp32 matrix
+//            cores (v_mfma_f32_16x16x4_f32: the 16 hands are the N dimension; weight fragments straight from
+//            L2 in operand order, the 16 x 160 activation operand lives in registers), staged through LDS;
+//   phase 3  skinning transforms T[v] = sum_u w[v][u] A_u as a second small product on the matrix cores (per hand:
+//            12 transform entries x 16 joints x 16 vertices), applied to the posed vertices, camera translation;
+//            fingertip joints + projection at the end of the block that skinned the tip vertex.
+// Every output element is computed by one fixed instruction sequence, independent of the grid shape.
+struct ManoSideArgs {
+  hands_mano_consts c;
+  const float* blend_w;      // [2432][160] packed (hands_pack_mano_f32)
+  const float* blend_bias;   // [2432] = v_template
+  hands_mano_out o;
+  const float* rot;          // this side's rows: (B,16,3,3) or (B,48) axis-angle
+  const float* betas;        // (B, ld_betas)
+  const float* cam_wp;       // (B,3)
+};
+struct ManoHeadsArgs {
+  ManoSideArgs side[2];
+  const float* K;            // (B,3,3) shared by both sides
+  int ld_betas, B, vsplit;
+  float img_res, min_s;
+};
+
+constexpr int MH = 16;             // hands per block = MFMA N
+constexpr int CHUNK_V = 64;        // vertices per chunk
+constexpr int CHUNK_M = 192;       // blend outputs per chunk = 12 row tiles of 16
+constexpr int NCHUNK = (NV + CHUNK_V - 1) / CHUNK_V;   // 13
+constexpr int VROW = 196;          // LDS row of the v_posed stage (49 x 16 B: odd)
+constexpr int BROW = 164;          // LDS row of the blend input (41 x 16 B: odd)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool AA_INPUT>
+__global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
+  // phase-1 scratch (joint rotations, rest joints, global transforms) is dead once A is built: it shares its
+  // bytes with the v_posed stage of phases 2-3
+  __shared__ __attribute__((aligned(16))) float sScratch[2 * MH * VROW];
+  static_assert(MH * NJ * (9 + 3 + 12) <= 2 * MH * VROW, "phase-1 scratch must fit in the stage buffers");
+  float (*sR)[NJ][9] = reinterpret_cast<float (*)[NJ][9]>(sScratch);
+  float (*sJ)[NJ][3] = reinterpret_cast<float (*)[NJ][3]>(sScratch + MH * NJ * 9);
+  float (*sG)[NJ][12] = reinterpret_cast<float (*)[NJ][12]>(sScratch + MH * NJ * 12);
+  float (*sV)[MH][VROW] = reinterpret_cast<float (*)[MH][VROW]>(sScratch);
+  __shared__ float sA[MH][NJ * 12];
+  __shared__ __attribute__((aligned(16))) float sBin[MH][BROW];
+  __shared__ float sCam[MH][3];
+  __shared__ float sTip[MH][5][3];
+  const ManoSideArgs& S = a.side[blockIdx.y];
+  const hands_mano_consts& c = S.c;
+  const int tid = threadIdx.x;
+  const int b0 = blockIdx.x * MH;
+  const int B = a.B;
+
+  // ---- phase 1: pose, joints, forward kinematics (one thread per hand-joint) ------------------------------
+  {
+    const int h = tid >> 4, j = tid & 15;
+    const int b = b0 + h;
+    const bool live = b < B;
+    if (live) {
+      float aa[3], R[9];
+      if constexpr (AA_INPUT) {
+        const float* src = S.rot + ((long long)b * NJ + j) * 3;
+        aa[0] = src[0]; aa[1] = src[1]; aa[2] = src[2];
+      } else {
+        hands::matrix_to_axis_angle(S.rot + ((long long)b * NJ + j) * 9, aa);
+      }
+      aa[0] += c.pose_mean[3 * j + 0];
+      aa[1] += c.pose_mean[3 * j + 1];
+      aa[2] += c.pose_mean[3 * j + 2];
+      hands::rodrigues(aa, R);
+#pragma unroll
+      for (int e = 0; e < 9; ++e) sR[h][j][e] = R[e];
+      const float* be = S.betas + (long long)b * a.ld_betas;
+      float* row = sBin[h];
+      if (j >= 1) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) row[10 + (j - 1) * 9 + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+      }
+      if (j < 10) row[j] = be[j];
+      if (j < 15) row[145 + j] = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        float acc = c.J_template[3 * j + cc];
+        const float* js = c.J_shapedirs + (3 * j + cc) * 10;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc += js[k] * be[k];
+        sJ[h][j][cc] = acc;
+      }
+      if (j == 0) {
+        // weak_perspective_to_perspective_torch (camera.py:456-474) with focal = (K00 + K11)/2
+        const float* Kb = a.K + (long long)b * 9;
+        const float f = (Kb[0] + Kb[4]) / 2.0f;
+        const float s = fmaxf(S.cam_wp[b * 3 + 0], a.min_s);
+        sCam[h][0] = S.cam_wp[b * 3 + 1];
+        sCam[h][1] = S.cam_wp[b * 3 + 2];
+        sCam[h][2] = 2.0f * f / (a.img_res * s + 1e-9f);
+      }
+    } else {
+      for (int e = j; e < 160; e += NJ) sBin[h][e] = 0.f;   // dead rows feed zeros to the matrix cores
+    }
+    __syncthreads();
+    const int dj = depth_of(j), pj = parent_of(j);
+    for (int level = 0; level < 4; ++level) {
+      if (live && dj == level) {
+        float* g = sG[h][j];
+        const float* r = sR[h][j];
+        if (level == 0) {
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr) {
+            g[rr * 4 + 0] = r[rr * 3 + 0]; g[rr * 4 + 1] = r[rr * 3 + 1]; g[rr * 4 + 2] = r[rr * 3 + 2];
+            g[rr * 4 + 3] = sJ[h][0][rr];
+          }
+        } else {
+          const float* gp = sG[h][pj];
+          const float t0 = sJ[h][j][0] - sJ[h][pj][0], t1 = sJ[h][j][1] - sJ[h][pj][1],
+                      t2 = sJ[h][j][2] - sJ[h][pj][2];
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr) {
+            const float p0 = gp[rr * 4 + 0], p1 = gp[rr * 4 + 1], p2 = gp[rr * 4 + 2], p3 = gp[rr * 4 + 3];
+            g[rr * 4 + 0] = p0 * r[0] + p1 * r[3] + p2 * r[6];
+            g[rr * 4 + 1] = p0 * r[1] + p1 * r[4] + p2 * r[7];
+            g[rr * 4 + 2] = p0 * r[2] + p1 * r[5] + p2 * r[8];
+            g[rr * 4 + 3] = p0 * t0 + p1 * t1 + p2 * t2 + p3;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (live) {
+      const float* g = sG[h][j];
+      float* am = sA[h] + j * 12;
+      const float j0 = sJ[h][j][0], j1 = sJ[h][j][1], j2 = sJ[h][j][2];
+      const float cx = sCam[h][0], cy = sCam[h][1], cz = sCam[h][2];
+      float p[3];
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {
+        am[rr * 4 + 0] = g[rr * 4 + 0]; am[rr * 4 + 1] = g[rr * 4 + 1]; am[rr * 4 + 2] = g[rr * 4 + 2];
+        am[rr * 4 + 3] = g[rr * 4 + 3] - (g[rr * 4 + 0] * j0 + g[rr * 4 + 1] * j1 + g[rr * 4 + 2] * j2);
+        p[rr] = g[rr * 4 + 3];
+      }
+      if (blockIdx.z == 0) {       // the 16 posed joints + camera outputs: written by the first vertex-range block
+        float* dj3 = S.o.joints3d + ((long long)b * 21 + j) * 3;
+        dj3[0] = p[0]; dj3[1] = p[1]; dj3[2] = p[2];
+        const float px = p[0] + cx, py = p[1] + cy, pz = p[2] + cz;
+        float* dc = S.o.j3d_cam + ((long long)b * 21 + j) * 3;
+        dc[0] = px; dc[1] = py; dc[2] = pz;
+        const float* Kb = a.K + (long long)b * 9;
+        const float hx = Kb[0] * px + Kb[1] * py + Kb[2] * pz;
+        const float hy = Kb[3] * px + Kb[4] * py + Kb[5] * pz;
+        const float hz = Kb[6] * px + Kb[7] * py + Kb[8] * pz;
+        float* d2 = S.o.j2d_norm + ((long long)b * 21 + j) * 2;
+        d2[0] = 2.0f * (hx / hz) / a.img_res - 1.0f;
+        d2[1] = 2.0f * (hy / hz) / a.img_res - 1.0f;
+        if (j < 3) S.o.cam_t[b * 3 + j] = sCam[h][j];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- phase 2 + 3 per chunk --------------------------------------------------------------------------------
+  const int lane = tid & 63, wave = tid >> 6;
+  const int mh = lane & 15, g = lane >> 4;           // MFMA column (hand) and k-group
+  float4 bfrag[10];                                  // this lane's blend-input operand: k = 16*s + 4*g + e
+#pragma unroll
+  for (int s4 = 0; s4 < 10; ++s4) bfrag[s4] = *reinterpret_cast<const float4*>(&sBin[mh][16 * s4 + 4 * g]);
+
+  const int c0 = (int)((long long)blockIdx.z * NCHUNK / a.vsplit);
+  const int c1 = (int)((long long)(blockIdx.z + 1) * NCHUNK / a.vsplit);
+  // skin assignment: wave w owns the chunk's vertex tile w (16 vertices, MFMA column = lane & 15); lane group g
+  // (= lane >> 4) ends up with row g of each vertex's 3x4 skinning transform, i.e. computes output coordinate g
+  int tip[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) tip[t] = c.tip_ids[t];
+  const int e12 = lane & 15;                         // MFMA row of the transform GEMM: entry e of A_u (12 used)
+
+  for (int ch = c0; ch < c1; ++ch) {
+    float (*stage)[VROW] = sV[(ch - c0) & 1];
+    // -- blend GEMM of this chunk: wave w owns row tiles w, w+4, w+8; the three accumulation chains are
+    //    independent, so their MFMAs are issued round-robin (issue-bound instead of latency-bound) after all
+    //    thirty weight fragments have been requested
+    {
+      float4 wf[3][10];
+      f32x4 acc[3];
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt) {
+        int m0 = ch * CHUNK_M + (wave + 4 * tt) * 16;
+        m0 = m0 < 2432 ? m0 : 2432 - 16;               // past the packed matrix: recompute its (all-zero) last tile
+        const float* wr = S.blend_w + (size_t)(m0 + mh) * 160 + 4 * g;
+#pragma unroll
+        for (int s4 = 0; s4 < 10; ++s4) wf[tt][s4] = *reinterpret_cast<const float4*>(wr + 16 * s4);
+        const float4 bias = *reinterpret_cast<const float4*>(S.blend_bias + m0 + 4 * g);
+        acc[tt][0] = bias.x; acc[tt][1] = bias.y; acc[tt][2] = bias.z; acc[tt][3] = bias.w;
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 10; ++s4) {
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tt][s4].x, bfrag[s4].x, acc[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tt][s4].y, bfrag[s4].y, acc[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tt][s4].z, bfrag[s4].z, acc[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tt][s4].w, bfrag[s4].w, acc[tt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt)
+        *reinterpret_cast<float4*>(&stage[mh][(wave + 4 * tt) * 16 + 4 * g]) =
+            make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
+    }
+    __syncthreads();
+    // -- skinning: T[v][h] = sum_u w[v][u] A_h[u] as a (12 x 16 joints) x (16 joints x 16 vertices) product per hand
+    //    on the matrix cores; lane (vertex, g < 3) then holds row g of T and applies it to the posed vertex
+    const int vl = wave * 16 + (lane & 15);
+    const int v = ch * CHUNK_V + vl;
+    const bool v_ok = v < NV;
+    float wreg[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) wreg[s4] = v_ok ? c.lbs_weights[v * NJ + 4 * s4 + g] : 0.f;
+    int tip_slot = -1;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) tip_slot = (v == tip[t]) ? t : tip_slot;
+    for (int h0 = 0; h0 < MH; h0 += 4) {
+      f32x4 T[4];
+      float av[4][4];
+#pragma unroll
+      for (int hh = 0; hh < 4; ++hh) {
+        const float* am = sA[h0 + hh];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) av[hh][s4] = e12 < 12 ? am[(4 * s4 + g) * 12 + e12] : 0.f;
+        T[hh][0] = 0.f; T[hh][1] = 0.f; T[hh][2] = 0.f; T[hh][3] = 0.f;
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) T[hh] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[hh][s4], wreg[s4], T[hh], 0, 0, 0);
+      }
+#pragma unroll
+      for (int hh = 0; hh < 4; ++hh) {
+        const int h = h0 + hh;
+        const int b = b0 + h;
+        if (v_ok && g < 3 && b < B) {
+          const float x = stage[h][3 * vl + 0], y = stage[h][3 * vl + 1], z = stage[h][3 * vl + 2];
+          const float o = T[hh][0] * x + T[hh][1] * y + T[hh][2] * z + T[hh][3];
+          stage[h][3 * vl + g] = o;                  // in place: every lane of the wave has read x, y, z by now
+          if (tip_slot >= 0) sTip[h][tip_slot][g] = o;
+        }
+      }
+    }
+    // the wave's 16 vertices x 3 coordinates of every hand are 48 consecutive floats both in the stage and in
+    // the output arrays: write them back 8 bytes per lane (hand rows are 9336 B apart: 8-byte aligned)
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      const int idx = it * 64 + lane;
+      const int h = idx / 24, k2 = (idx - 24 * h) * 2;
+      const int m = ch * CHUNK_M + wave * 48 + k2;   // first of the two output floats (vertex-major, 3 per vertex)
+      const int b = b0 + h;
+      if (b < B && m < NV * 3) {
+        const float2 o2 = *reinterpret_cast<const float2*>(&stage[h][wave * 48 + k2]);
+        const int c0i = m % 3, c1i = (m + 1) % 3;
+        *reinterpret_cast<float2*>(S.o.vertices + (long long)b * (NV * 3) + m) = o2;
+        *reinterpret_cast<float2*>(S.o.v3d_cam + (long long)b * (NV * 3) + m) =
+            make_float2(o2.x + sCam[h][c0i], o2.y + sCam[h][c1i]);
+      }
+    }
+    // the next chunk's GEMM writes the other stage buffer; this one is rewritten two chunks later, after the
+    // barrier of the next iteration
+  }
+  __syncthreads();
+  // ---- fingertip joints 16..20 of the tips whose vertex this block skinned: joints3d, camera space, projection
+  if (tid < MH * 5) {
+    const int h = tid / 5, t = tid - 5 * h;
+    const int b = b0 + h;
+    const int tch = tip[t] / CHUNK_V;
+    if (b < B && tch >= c0 && tch < c1) {
+      const float ox = sTip[h][t][0], oy = sTip[h][t][1], oz = sTip[h][t][2];
+      const float cx = sCam[h][0], cy = sCam[h][1], cz = sCam[h][2];
+      float* dj3 = S.o.joints3d + ((long long)b * 21 + 16 + t) * 3;
+      dj3[0] = ox; dj3[1] = oy; dj3[2] = oz;
+      const float px = ox + cx, py = oy + cy, pz = oz + cz;
+      float* dcj = S.o.j3d_cam + ((long long)b * 21 + 16 + t) * 3;
+      dcj[0] = px; dcj[1] = py; dcj[2] = pz;
+      const float* Kb = a.K + (long long)b * 9;
+      const float hx = Kb[0] * px + Kb[1] * py + Kb[2] * pz;
+      const float hy = Kb[3] * px + Kb[4] * py + Kb[5] * pz;
+      const float hz = Kb[6] * px + Kb[7] * py + Kb[8] * pz;
+      float* d2 = S.o.j2d_norm + ((long long)b * 21 + 16 + t) * 2;
+      d2[0] = 2.0f * (hx / hz) / a.img_res - 1.0f;
+      d2[1] = 2.0f * (hy / hz) / a.img_res - 1.0f;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int hands_mano_heads_f32(const hands_mano_side* sides, int n_sides, const float* K, int ld_betas, float img_res,
+                         float min_s, int B, int axis_angle_input, hands_stream_t stream) {
+  if (!sides || n_sides < 1 || n_sides > 2 || !K || B <= 0 || ld_betas < 10) return HANDS_EINVAL;
+  ManoHeadsArgs a;
+  for (int s = 0; s < n_sides; ++s) {
+    const hands_mano_side& h = sides[s];
+    if (!h.consts.pose_mean || !h.consts.J_template || !h.consts.J_shapedirs || !h.consts.lbs_weights ||
+        !h.consts.tip_ids || !h.blend_w || !h.blend_bias || !h.rot || !h.betas || !h.cam_wp || !h.out.vertices ||
+        !h.out.joints3d || !h.out.v3d_cam || !h.out.j3d_cam || !h.out.j2d_norm || !h.out.cam_t)
+      return HANDS_EINVAL;
+    a.side[s].c = h.consts; a.side[s].blend_w = h.blend_w; a.side[s].blend_bias = h.blend_bias; a.side[s].o = h.out;
+    a.side[s].rot = h.rot; a.side[s].betas = h.betas; a.side[s].cam_wp = h.cam_wp;
+  }
+  if (n_sides == 1) a.side[1] = a.side[0];
+  a.K = K; a.ld_betas = ld_betas; a.B = B; a.img_res = img_res; a.min_s = min_s;
+  const int nb = (B + MH - 1) / MH;
+  // split the 13 vertex chunks over blockIdx.z until ~2 blocks per CU exist (results do not depend on it)
+  int vs = 512 / (nb * n_sides);
+  vs = vs < 1 ? 1 : (vs > NCHUNK ? NCHUNK : vs);
+  a.vsplit = vs;
+  dim3 grid((unsigned)nb, (unsigned)n_sides, (unsigned)vs);
+  if (axis_angle_input) hipLaunchKernelGGL(mano_heads_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(mano_heads_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  HANDS_LAUNCH_CHECK();
+}
 
 int hands_mano_pose_f32(const hands_mano_consts* c, const float* rotmat, const float* betas, int ld_betas,
                         float* blend_in, int ld_blend, float* A, float* joints16, int B,

@@ -25,13 +25,14 @@ class ConvEngine:
         self.overlap = True           # run independent jobs (trunks, heads, crop chunks) on side HIP streams
         self.fuse_stem_pool = True    # stem conv + BN + act + max-pool as one kernel (csrc/stem_pool.hip)
         self.fuse_downsample = True   # first block of a stage: conv3 + downsample + add + ReLU as one two-source GEMM
+        self.fuse_mano = True         # MANOHead.forward of both hands as one launch (hands_mano_heads_f32)
         self.hook = None              # callable(phase, pc, npix, stream_handle, has_res, kernel): bench.py brackets
                                       # every MFMA launch (conv_igemm and the fused stem) with events
         self._splitk_ws = {}          # (device, stream handle) -> workspace tensor
 
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
-        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample"):
+        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "fuse_mano"):
             setattr(e, k, getattr(self, k))
         return e
 

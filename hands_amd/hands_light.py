@@ -28,12 +28,12 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import ManoConsts, ManoOut, check, ptr
+from ._lib import ManoConsts, ManoOut, ManoSide, check, ptr
 from .engine import DEFAULT_ENGINE, ConvEngine, EngineSwitches
 from .mano import ManoLayer, build_mano_asset
 from .packing import (HMR_VEC, PackedConv, fold_bn, hmr_state_columns, pack_conv, pack_conv1x1_dual,
                       pack_linear, pack_mano)
-from .xdict import prefix_dict, xdict
+from .xdict import prefix_dict, stream_xdict, xdict
 
 RESNET50_LAYERS = (3, 4, 6, 3)
 
@@ -116,25 +116,42 @@ class MANOHead(nn.Module):
 def run_mano_heads(L, mano_r, mano_l, rot, shape, cam, cam_init, K, img_res, bz, stream, buf, engine=None):
     """MANOHead.forward for the right (rows [0,bz)) and left (rows [bz,2bz)) hands
     (src/nets/hand_heads/mano_head.py:21-65) + the `cam_t.wp.init` / `mano.` prefixing of
-    model.py:392-399.  rot (2bz,16,3,3), shape (2bz,10), cam / cam_init (2bz,3), K (bz,3,3)."""
+    model.py:392-399.  rot (2bz,16,3,3), shape (2bz,10), cam / cam_init (2bz,3), K (bz,3,3).
+    One launch for both hands (hands_mano_heads_f32); ``engine.fuse_mano = False`` keeps the three-launch
+    chain per side (pose -> blend GEMM -> skin), which the tests compare it with."""
     dev = rot.device
-    blend_in = buf("blend_in", bz * 160)
-    Abuf, j16 = buf("mano_A", bz * 192), buf("mano_j16", bz * 48)
-    vposed = buf("vposed", bz * 2336)
+    engine = engine or DEFAULT_ENGINE
+    fused = getattr(engine, "fuse_mano", True)
     output = xdict()
-    for side, (mp, post) in enumerate(((mano_r, ".r"), (mano_l, ".l"))):
+    outs = []
+    for side in range(2):
+        outs.append({"vertices": torch.empty(bz, 778, 3, device=dev), "joints3d": torch.empty(bz, 21, 3, device=dev),
+                     "v3d.cam": torch.empty(bz, 778, 3, device=dev), "j3d.cam": torch.empty(bz, 21, 3, device=dev),
+                     "j2d.norm": torch.empty(bz, 21, 2, device=dev), "cam_t": torch.empty(bz, 3, device=dev)})
+    mouts = [ManoOut(ptr(o["vertices"]), ptr(o["joints3d"]), ptr(o["v3d.cam"]), ptr(o["j3d.cam"]),
+                     ptr(o["j2d.norm"]), ptr(o["cam_t"])) for o in outs]
+    if fused:
+        sides = (ManoSide * 2)()
+        for side, mp in enumerate((mano_r, mano_l)):
+            ro = side * bz
+            sides[side] = ManoSide(mp["consts"], ptr(mp["blend"].w), ptr(mp["blend"].bias), ptr(rot, ro * 144),
+                                   ptr(shape, ro * 10), ptr(cam, ro * 3), mouts[side])
+        check(L.hands_mano_heads_f32(sides, 2, ptr(K), 10, img_res, 0.1, bz, 0, stream), "mano_heads")
+    else:
+        blend_in = buf("blend_in", bz * 160)
+        Abuf, j16 = buf("mano_A", bz * 192), buf("mano_j16", bz * 48)
+        vposed = buf("vposed", bz * 2336)
+        for side, mp in enumerate((mano_r, mano_l)):
+            ro = side * bz
+            check(L.hands_mano_pose_f32(C.byref(mp["consts"]), ptr(rot, ro * 144), ptr(shape, ro * 10), 10,
+                                        ptr(blend_in), 160, ptr(Abuf), ptr(j16), bz, stream), "mano_pose")
+            engine.conv(L, mp["blend"], blend_in, bz, 1, 1, vposed, False, stream)
+            check(L.hands_mano_skin_f32(C.byref(mp["consts"]), ptr(vposed), 2336, ptr(Abuf), ptr(j16),
+                                        ptr(cam, ro * 3), ptr(K), img_res, 0.1, C.byref(mouts[side]), bz, stream),
+                  "mano_skin")
+    for side, post in enumerate((".r", ".l")):
         ro = side * bz
-        check(L.hands_mano_pose_f32(C.byref(mp["consts"]), ptr(rot, ro * 144), ptr(shape, ro * 10), 10,
-                                    ptr(blend_in), 160, ptr(Abuf), ptr(j16), bz, stream), "mano_pose")
-        (engine or DEFAULT_ENGINE).conv(L, mp["blend"], blend_in, bz, 1, 1, vposed, False, stream)
-        o = {"vertices": torch.empty(bz, 778, 3, device=dev), "joints3d": torch.empty(bz, 21, 3, device=dev),
-             "v3d.cam": torch.empty(bz, 778, 3, device=dev), "j3d.cam": torch.empty(bz, 21, 3, device=dev),
-             "j2d.norm": torch.empty(bz, 21, 2, device=dev), "cam_t": torch.empty(bz, 3, device=dev)}
-        mo = ManoOut(ptr(o["vertices"]), ptr(o["joints3d"]), ptr(o["v3d.cam"]), ptr(o["j3d.cam"]),
-                     ptr(o["j2d.norm"]), ptr(o["cam_t"]))
-        check(L.hands_mano_skin_f32(C.byref(mp["consts"]), ptr(vposed), 2336, ptr(Abuf), ptr(j16),
-                                    ptr(cam, ro * 3), ptr(K), img_res, 0.1, C.byref(mo), bz, stream),
-              "mano_skin")
+        o = outs[side]
         md = xdict()                                           # key order of mano_head.py:53-61
         md["cam_t.wp"] = cam[ro:ro + bz]
         md["cam_t"] = o["cam_t"]
@@ -149,6 +166,9 @@ def run_mano_heads(L, mano_r, mano_l, rot, shape, cam, cam_init, K, img_res, bz,
         md["cam_t.wp.init" + post] = cam_init[ro:ro + bz]       # model.py:392-393
         output.merge(prefix_dict(md, "mano."))                  # model.py:395-399
     return output
+
+
+run_mano_heads.launches_per_step = 1
 
 
 def mano_consts(m):
@@ -191,6 +211,8 @@ class HandsLight(EngineSwitches, nn.Module):
         super().__init__()
         self.engine = ConvEngine()
         self.trunk_chunks = (1, 2)    # (global, hand) trunk jobs, one HIP stream each
+        self.async_tail = True        # tail of the forward on its own stream, joined at first use of the result
+        self._calls = 0
         args = args if args is not None else DEFAULT_ARGS
         get = (lambda k, d=None: args.get(k, d)) if hasattr(args, "get") else (lambda k, d=None: getattr(args, k, d))
         self.args = args
@@ -430,11 +452,25 @@ class HandsLight(EngineSwitches, nn.Module):
         #    HIP streams: each conv launch is only 400-3000 workgroups on 256 CUs, and workgroups of
         #    the other streams fill its tail (and HBM-bound layers overlap with MFMA-bound ones).
         main = torch.cuda.current_stream(dev)
-        feat_vec = buf("feat_vec", bz * F)
+        # The tail of the forward (feature_conv, HMR heads, MANO, grasp: ~3 ms of launch-bound work) runs on its
+        # own stream and is NOT joined back: the result is a stream_xdict that makes the consumer's stream
+        # wait at first access, so the next forward's trunks start under this forward's tail.  The trunk
+        # outputs the tail reads are double-buffered by call parity; everything the tail reads from the
+        # caller (angles, intrinsics, flags) is copied on the caller's stream first.
+        async_tail = bool(self.async_tail and self.engine.overlap and not torch.cuda.is_current_stream_capturing())
+        par = self._calls & 1 if async_tail else 0
+        self._calls += 1
+        if not torch.cuda.is_current_stream_capturing():
+            # the tail two calls ago read these feature buffers (long finished); a synchronous call waits for
+            # every earlier asynchronous tail
+            for q in ((par,) if async_tail else (0, 1)):
+                prev_tail = self._ws.get(f"tail_done{q}")
+                if prev_tail is not None:
+                    main.wait_event(prev_tail)
         x4g = buf("x4g", bz * res * res * 4)
         x4 = buf("x4", B2 * res * res * 4)
-        featg = buf("feat_g", bz * 49 * F)
-        feath = buf("feat_h", B2 * 49 * F)
+        featg = buf(f"feat_g{par}", bz * 49 * F)
+        feath = buf(f"feat_h{par}", B2 * 49 * F)
         gch, hch = self.trunk_chunks if self.engine.overlap else (1, 1)
         gch, hch = max(1, min(gch, bz)), max(1, min(hch, B2))
         jobs = []   # (weights, images, x4 buffer, first sample, n samples, out buffer, is_global)
@@ -467,12 +503,39 @@ class HandsLight(EngineSwitches, nn.Module):
             main.wait_event(ev)
         assert fh * fw == 49
         HW = fh * fw
+        # small per-sample inputs the tail reads: private copies made on the caller's stream
+        center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
+        corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0)
+        flipped = meta_info["is_flipped"].to(device=dev, dtype=torch.int64).contiguous()
+        if async_tail:
+            K, flipped = K.clone(), flipped.clone()
+            tail = self._side_stream(dev, "tail")
+            evt = torch.cuda.Event()
+            evt.record(main)
+            tail.wait_event(evt)
+            for t in (center, corner, K, flipped):
+                t.record_stream(tail)
+        else:
+            tail = main
+        with torch.cuda.stream(tail):
+            output = self._forward_tail(L, P, dev, tail, bz, fh, fw, featg, feath, center, corner, K, flipped)
+        if not async_tail:
+            return output
+        ready = torch.cuda.Event()
+        ready.record(tail)
+        self._ws[f"tail_done{par}"] = ready
+        return stream_xdict(output, ready, dev)
+
+    def _forward_tail(self, L, P, dev, main, bz, fh, fw, featg, feath, center, corner, K, flipped):
+        """Everything after the trunks (model.py:196-411), enqueued on ``main`` (the tail stream)."""
+        B2, F, HW = 2 * bz, self.feat_dim, fh * fw
+        stream = main.cuda_stream
+        buf = lambda n, numel: self._buf(n, numel, dev)
+        feat_vec = buf("feat_vec", bz * F)
         # sum-pool (model.py:196)
         check(L.hands_sumpool_nhwc_f32(ptr(featg), ptr(feat_vec), bz, HW, F, F, stream), "sumpool")
 
         # -- KPE concat (model.py:258-271) ----------------------------------------------------------
-        center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
-        corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0)
         Cc = F + 20 * self.n_freq
         cat = buf("cat", B2 * HW * Cc)
         check(L.hands_kpe_concat_f32(ptr(feath), ptr(featg), ptr(center), ptr(corner), ptr(cat), B2, bz,
@@ -528,7 +591,6 @@ class HandsLight(EngineSwitches, nn.Module):
         caminit = caminit4[: B2 * 4].view(B2, 4)[:, :3].contiguous()
 
         # -- is_flipped swap (model.py:341-368), per sample on device ----------------------------
-        flipped = meta_info["is_flipped"].to(device=dev, dtype=torch.int64).contiguous()
         rot_m = torch.empty(B2, 16, 3, 3, device=dev)
         shape_m = torch.empty(B2, 10, device=dev)
         cam_m = torch.empty(B2, 3, device=dev)

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import ManoOut, check, ptr
+from ._lib import ManoOut, ManoSide, check, ptr
 from .engine import DEFAULT_ENGINE
 from .hands_light import DEFAULT_ARGS, HandsLight
 from .xdict import xdict
@@ -66,15 +66,12 @@ class HandsWrapper(nn.Module):
             pose, beta, full = f32(targets[f"mano.pose.{h}"]), f32(targets[f"mano.beta.{h}"]), f32(targets[f"mano.j3d.full.{h}"])
             B = pose.shape[0]
             assert pose.shape == (B, 48) and beta.shape == (B, 10) and full.shape == (B, 21, 3)
-            blend_in, A, j16, vposed = new(B, 160), new(B, 192), new(B, 48), new(B, 2336)
-            check(L.hands_mano_pose_aa_f32(C.byref(mp["consts"]), ptr(pose), ptr(beta), 10, ptr(blend_in), 160, ptr(A),
-                                           ptr(j16), B, stream), "mano_pose_aa")
-            getattr(self.model, "engine", DEFAULT_ENGINE).conv(L, mp["blend"], blend_in, B, 1, 1, vposed, False, stream)
             o = {k: new(B, n, 3) for k, n in (("vertices", 778), ("joints3d", 21), ("v3d", 778), ("j3d", 21))}
             j2d, cam_t_unused, one_cam = new(B, 21, 2), new(B, 3), torch.ones(B, 3, device=dev)
             mo = ManoOut(ptr(o["vertices"]), ptr(o["joints3d"]), ptr(o["v3d"]), ptr(o["j3d"]), ptr(j2d), ptr(cam_t_unused))
-            check(L.hands_mano_skin_f32(C.byref(mp["consts"]), ptr(vposed), 2336, ptr(A), ptr(j16), ptr(one_cam), ptr(K),
-                                        img_res, 0.1, C.byref(mo), B, stream), "mano_skin")
+            side = (ManoSide * 1)(ManoSide(mp["consts"], ptr(mp["blend"].w), ptr(mp["blend"].bias), ptr(pose), ptr(beta),
+                                           ptr(one_cam), mo))
+            check(L.hands_mano_heads_f32(side, 1, ptr(K), 10, img_res, 0.1, B, 1, stream), "mano_heads (axis-angle)")
             v3d_cam, cam_t, cam_wp = new(B, 778, 3), new(B, 3), new(B, 3)
             check(L.hands_gt_targets_f32(ptr(o["joints3d"]), ptr(o["vertices"]), ptr(full), ptr(K), img_res, ptr(v3d_cam),
                                          ptr(cam_t), ptr(cam_wp), B, 778, stream), "gt_targets")

@@ -166,6 +166,70 @@ class xdict(dict):
         torch.save(self.to(dev), path)
 
 
+class stream_xdict(xdict):
+    """An xdict whose tensors are being produced on a side HIP stream (the tail of ``HandsLight.forward``:
+    feature_conv, HMR heads, MANO, grasp), so that the caller's stream is free to start the next forward's
+    trunks meanwhile.  Plain PyTorch stream semantics are kept at the point of use: the first access of any
+    kind (``d[k]``, iteration, ``len``, ``dict(d)``, ``.items()``, ``.detach()`` ...) makes the CURRENT stream
+    wait for the producer and registers the tensors with it; from then on it is an ordinary xdict.  A caller
+    that never looks at the result (a throughput loop) never waits; ``torch.cuda.synchronize()`` covers the
+    side stream as it covers every stream."""
+
+    def __init__(self, pending: dict, ready_event, device):
+        super().__init__()
+        self.__dict__["_pending"] = pending
+        self.__dict__["_ready"] = ready_event
+        self.__dict__["_device"] = device
+
+    def _join(self):
+        p = self.__dict__.get("_pending")
+        if p is not None:
+            self.__dict__["_pending"] = None
+            cur = torch.cuda.current_stream(self.__dict__["_device"])
+            cur.wait_event(self.__dict__["_ready"])
+            for v in p.values():
+                if isinstance(v, torch.Tensor) and v.is_cuda:
+                    v.record_stream(cur)
+            dict.update(self, p)
+
+    @property
+    def is_pending(self):
+        return self.__dict__.get("_pending") is not None
+
+
+def _joined(name):
+    base = getattr(dict, name)
+
+    def method(self, *a, **k):
+        self._join()
+        return base(self, *a, **k)
+    method.__name__ = name
+    return method
+
+
+# every Python-level entry point joins first; overriding __iter__ / keys also takes dict(d), {**d} and
+# dict.update(other, d) off CPython's exact-dict fast path, so they go through these methods too
+for _n in ("__getitem__", "__iter__", "__len__", "__contains__", "keys", "values", "items", "get", "__repr__",
+           "__eq__", "__ne__", "pop", "popitem", "copy", "update", "setdefault", "__delitem__", "__reversed__",
+           "__or__", "__ror__", "__ior__", "clear", "__reduce_ex__", "__sizeof__"):
+    setattr(stream_xdict, _n, _joined(_n))
+
+
+def _xd_setitem(self, key, val):
+    self._join()
+    xdict.__setitem__(self, key, val)
+
+
+def _xd_overwrite(self, k, v):
+    self._join()
+    dict.__setitem__(self, k, v)
+
+
+stream_xdict.__setitem__ = _xd_setitem
+stream_xdict.overwrite = _xd_overwrite
+stream_xdict.__hash__ = None
+
+
 def prefix_dict(mydict, prefix):
     """reference: common/ld_utils.py:12-14 (returns a plain dict)."""
     return {prefix + k: v for k, v in mydict.items()}

@@ -203,6 +203,26 @@ int hands_mano_skin_f32(const hands_mano_consts* c, const float* v_posed, int ld
                         const float* K, float img_res, float min_s, const hands_mano_out* out,
                         int B, hands_stream_t stream);
 
+/* MANOHead.forward for ONE or BOTH hands in a single launch: everything hands_mano_pose_f32 ->
+ * hands_conv2d_nhwc_f32 (blend) -> hands_mano_skin_f32 compute, fused (pose / forward kinematics, the
+ * 2334 x 145 blend contraction on the fp32 matrix cores with the 16 hands of a block as the MFMA N
+ * dimension, skinning, camera, projection).  sides[s] carries that side's constants (hands_pack_mano_f32),
+ * inputs (rot (B,16,3,3) rotation matrices -- or (B,48) axis-angle when axis_angle_input != 0 --, betas
+ * (B, ld_betas), cam_wp (B,3)) and outputs; K (B,3,3) is shared.  Replaces mano_head.py:21-65 for
+ * mano_r and mano_l (model.py:378-390) and the ground-truth MANO pass (process_arctic.py:16-40). */
+typedef struct hands_mano_side {
+  hands_mano_consts consts;
+  const float* blend_w;     /* [2432][160] */
+  const float* blend_bias;  /* [2432] */
+  const float* rot;
+  const float* betas;
+  const float* cam_wp;
+  hands_mano_out out;
+} hands_mano_side;
+
+int hands_mano_heads_f32(const hands_mano_side* sides, int n_sides, const float* K, int ld_betas,
+                         float img_res, float min_s, int B, int axis_angle_input, hands_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * hamer_light (ViT-H/16 + cross-attention decoder head): src/models/hamer_light/.
  * GEMMs (patch embed, qkv, proj, MLP, to_kv, decoders ...) run on hands_conv2d_nhwc_f32.

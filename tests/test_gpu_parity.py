@@ -336,6 +336,89 @@ def _run_mano(asset, rotmat, betas, cam, K):
     return {k: v.cpu() for k, v in o.items()}
 
 
+def _run_mano_fused(assets, rot2, betas2, cam2, K, aa_input=False, n_sides=2):
+    """hands_mano_heads_f32: both hands (rows [0,B) right, [B,2B) left) in ONE launch."""
+    L = _lib.lib()
+    B = K.shape[0]
+    mps = [pack_mano(a, DEV) for a in assets]
+    keep = [rot2.to(DEV).contiguous(), betas2.to(DEV).contiguous(), cam2.to(DEV).contiguous(), K.to(DEV).contiguous()]
+    per = rot2[0].numel()
+    sides = (_lib.ManoSide * n_sides)()
+    outs = []
+    for s_ in range(n_sides):
+        mp = mps[s_]
+        consts = _lib.ManoConsts(ptr(mp["pose_mean"]), ptr(mp["J_template"]), ptr(mp["J_shapedirs"]),
+                                 ptr(mp["lbs_weights"]), ptr(mp["tip_ids"]))
+        o = {"vertices": torch.full((B, 778, 3), float("nan"), device=DEV), "joints3d": torch.full((B, 21, 3), float("nan"), device=DEV),
+             "v3d.cam": torch.full((B, 778, 3), float("nan"), device=DEV), "j3d.cam": torch.full((B, 21, 3), float("nan"), device=DEV),
+             "j2d.norm": torch.full((B, 21, 2), float("nan"), device=DEV), "cam_t": torch.full((B, 3), float("nan"), device=DEV)}
+        mo = _lib.ManoOut(*[ptr(o[k]) for k in ("vertices", "joints3d", "v3d.cam", "j3d.cam", "j2d.norm", "cam_t")])
+        sides[s_] = _lib.ManoSide(consts, ptr(mp["blend"].w), ptr(mp["blend"].bias), ptr(keep[0], s_ * B * per),
+                                  ptr(keep[1], s_ * B * 10), ptr(keep[2], s_ * B * 3), mo)
+        outs.append(o)
+    check(L.hands_mano_heads_f32(sides, n_sides, ptr(keep[3]), 10, 224.0, 0.1, B, int(aa_input), _stream()), "mano_heads")
+    torch.cuda.synchronize()
+    return [{k: v.cpu() for k, v in o.items()} for o in outs]
+
+
+@pytest.mark.parametrize("B", [37, 1, 16, 130])
+def test_fused_two_hand_mano_vs_oracle_and_three_launch_chain(B):
+    """One launch for both hands (BASELINE configs[4]) against the oracle, the fp64 run of the restatement and
+    the three-launch chain; ragged hand counts (B % 16 != 0), identity / near-pi rotations, min_s clamp."""
+    assets = [synthetic_mano_asset(True), synthetic_mano_asset(False)]
+    rot, betas, cam, K = _mano_inputs(2 * B, 11 + B)
+    K = K[:B]
+    rot[0] = torch.eye(3)
+    if B > 2:
+        rot[1, :, :, :] = O.axis_angle_to_matrix(torch.tensor([[3.1415, 0.0, 0.0]]))[0]
+        cam[2, 0] = -0.5
+        rot[B + 1] = torch.eye(3)
+    got = _run_mano_fused(assets, rot, betas, cam, K)
+    for s_, asset in enumerate(assets):
+        sl = slice(s_ * B, (s_ + 1) * B)
+        ref = O.mano_head(rot[sl], betas[sl], cam[sl], K, asset, 224, "")
+        v64, j64 = O.mano_lbs(betas[sl], *torch.split(O.matrix_to_axis_angle(rot[sl].double().view(-1, 3, 3)).view(-1, 48), [3, 45], 1),
+                              asset, dtype=torch.float64)
+        g = got[s_]
+        assert all(torch.isfinite(v).all() for v in g.values())
+        assert (g["vertices"] - ref["vertices"]).abs().max().item() < 1e-6
+        assert (g["joints3d"] - ref["joints3d"]).abs().max().item() < 1e-6
+        assert (g["vertices"].double() - v64).abs().max().item() < 1e-6
+        assert (g["joints3d"].double() - j64).abs().max().item() < 1e-6
+        assert torch.allclose(g["cam_t"], ref["cam_t"], rtol=1e-6, atol=0)
+        assert torch.allclose(g["v3d.cam"], ref["v3d.cam"], rtol=2e-6, atol=2e-6)
+        assert torch.allclose(g["j3d.cam"], ref["j3d.cam"], rtol=2e-6, atol=2e-6)
+        assert (g["j2d.norm"] - ref["j2d.norm"]).abs().max().item() < 1e-5
+        assert torch.equal(g["joints3d"][:, 16:], g["vertices"][:, list(O.TIP_IDS)])
+        chain = _run_mano(asset, rot[sl], betas[sl], cam[sl], K)
+        assert (g["vertices"] - chain["vertices"]).abs().max().item() < 5e-7          # same math, other k order in the blend
+        assert torch.equal(g["cam_t"], chain["cam_t"])
+    # one side only == the same side of the two-side launch, bit for bit (grid shape never changes a result)
+    one = _run_mano_fused(assets[:1], rot[:B], betas[:B], cam[:B], K, n_sides=1)[0]
+    for k in one:
+        assert torch.equal(one[k], got[0][k]), k
+
+
+def test_fused_mano_axis_angle_input_and_batch_invariance():
+    """axis-angle input (ground-truth MANO parameters, process_arctic.py:16-21) and: hand i of a 1024-hand
+    launch equals hand i of a 3-hand launch bit for bit."""
+    assets = [synthetic_mano_asset(True), synthetic_mano_asset(False)]
+    B = 1024
+    rot, betas, cam, K = _mano_inputs(2 * B, 5)
+    K = K[:B]
+    big = _run_mano_fused(assets, rot, betas, cam, K)
+    idx = torch.tensor([0, 1, 2])
+    small = _run_mano_fused(assets, torch.cat([rot[idx], rot[B + idx]]), torch.cat([betas[idx], betas[B + idx]]),
+                            torch.cat([cam[idx], cam[B + idx]]), K[:3])
+    for s_ in range(2):
+        for k in small[s_]:
+            assert torch.equal(small[s_][k], big[s_][k][:3]), k
+    aa = O.matrix_to_axis_angle(rot.view(-1, 3, 3)).view(2 * B, 48)
+    via_aa = _run_mano_fused(assets, aa, betas, cam, K, aa_input=True)
+    for s_ in range(2):
+        assert (via_aa[s_]["vertices"] - big[s_]["vertices"]).abs().max().item() < 1e-6
+
+
 def _mano_inputs(B, seed):
     g = torch.Generator().manual_seed(seed)
     rot = O.rotation_6d_to_matrix(torch.randn(B * 16, 6, generator=g)).view(B, 16, 3, 3)
@@ -479,6 +562,36 @@ def test_replica_on_a_second_stream(gpu_model):
     for o in outs:
         for k in ref:
             assert torch.equal(o[k], ref[k]), k
+
+
+def test_async_tail_keeps_stream_semantics(gpu_model):
+    """The forward's tail runs on its own stream and the result joins at first use: results are bit-identical
+    to the synchronous path; inputs may be overwritten right after forward() returns; several un-consumed
+    forwards may be in flight (double-buffered trunk outputs)."""
+    from hands_amd.xdict import stream_xdict
+    inputs, meta_info = synthetic_inputs(4, 21, device=DEV)
+    meta_info["is_flipped"] = torch.tensor([0, 1, 0, 1], device=DEV)
+    gpu_model.async_tail = False
+    ref = {k: v.clone() for k, v in gpu_model(inputs, meta_info).items()}
+    other_in, other_meta = synthetic_inputs(4, 22, device=DEV)
+    ref2 = {k: v.clone() for k, v in gpu_model(other_in, other_meta).items()}
+    gpu_model.async_tail = True
+    torch.cuda.synchronize()
+    outs = []
+    for i in range(5):                                    # five forwards enqueued back to back, none consumed
+        src_in, src_meta = (inputs, meta_info) if i % 2 == 0 else (other_in, other_meta)
+        mine = {k: v.clone() for k, v in src_in.items()}
+        mm = {k: v.clone() for k, v in src_meta.items()}
+        o = gpu_model(mine, mm)
+        assert isinstance(o, stream_xdict) and o.is_pending
+        for v in list(mine.values()) + list(mm.values()):  # the caller reuses its input buffers immediately
+            v.zero_()
+        outs.append(o)
+    for i, o in enumerate(outs):
+        exp = ref if i % 2 == 0 else ref2
+        assert len(o) == 22 and not o.is_pending
+        for k in exp:
+            assert torch.equal(o[k], exp[k]), (i, k)
 
 
 def test_forward_vs_oracle_with_flips(recipe_sd, gpu_model):

@@ -46,6 +46,35 @@ def test_xdict_detach_and_invalid(capsys):
     assert m["v"].tolist() == [2, 2] and m["w"][0].item() == 2
 
 
+def test_stream_xdict_joins_at_first_use(monkeypatch):
+    """The asynchronous-tail result container: empty at the C level until ANY access makes the current stream
+    wait for the producer; dict(d), {**d}, merge and the xdict helpers all go through the join."""
+    from hands_amd.xdict import stream_xdict
+    waits = []
+
+    class _Stream:
+        def wait_event(self, ev):
+            waits.append(ev)
+
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda d=None: _Stream())
+    mk = lambda: stream_xdict({"a": torch.ones(2), "b": torch.zeros(3)}, object(), "cpu")
+    d = mk()
+    assert d.is_pending and dict.__len__(d) == 0 and not waits
+    assert sorted(dict(d)) == ["a", "b"] and len(waits) == 1 and not d.is_pending
+    assert d["a"].sum() == 2 and len(waits) == 1                       # joined once
+    for use in (lambda x: {**x}, lambda x: x.prefix("p."), lambda x: list(x), lambda x: len(x), lambda x: "a" in x,
+                lambda x: x.items(), lambda x: x.detach(), lambda x: x.get("a"), lambda x: x == {}, lambda x: repr(x)):
+        n, x = len(waits), mk()
+        use(x)
+        assert len(waits) == n + 1 and not x.is_pending, use
+    o, x = xdict({"c": 1}), mk()
+    o.merge(x)
+    assert sorted(o) == ["a", "b", "c"] and isinstance(x, xdict)
+    x = mk()
+    with pytest.raises(AssertionError):
+        x["a"] = 1                                                      # strict assignment still holds
+
+
 # ---- packing --------------------------------------------------------------------------------------
 def _packed_conv_reference(pc, x_nhwc):
     """Emulate the kernel's GEMM view on CPU with the PACKED weights (torch fp64)."""

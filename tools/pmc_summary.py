@@ -19,6 +19,19 @@ def total(fn, counter):
     return tot, len(disp)
 
 
+def by_grid(fn, counter):
+    """per (template instantiation, grid size): [dispatches, KB] -- which launch shapes carry the traffic"""
+    g = {}
+    for r in csv.DictReader(open(fn)):
+        if "conv_igemm_f32_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            inst = r["Kernel_Name"].split("<")[1].split(">")[0].replace(" ", "") if "<" in r["Kernel_Name"] else "?"
+            key = f"<{inst}> grid={r.get('Grid_Size', '?')}"
+            d = g.setdefault(key, [set(), 0.0])
+            d[0].add(r["Dispatch_Id"])
+            d[1] += float(r["Counter_Value"])
+    return {k: [len(v[0]), v[1]] for k, v in g.items()}
+
+
 f, nf = total(fetch_csv, "FETCH_SIZE")
 w, nw = total(write_csv, "WRITE_SIZE")
 assert nf == nw and nf > 0, (nf, nw)
@@ -28,5 +41,9 @@ res = {"workload": workload, "kernel": "conv_igemm_f32_kernel", "dispatches": nf
        "read_gb_per_launch": 2.0 * f * 1024 / nf / 1e9, "write_gb_per_launch": w * 1024 / nf / 1e9,
        "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --workload {workload} "
                   "--serial --steps 1 --warmup 1 --no-cpu-baseline"}
+gf, gw = by_grid(fetch_csv, "FETCH_SIZE"), by_grid(write_csv, "WRITE_SIZE")
+res["by_launch_shape_gb_per_launch"] = {
+    k: {"dispatches": gf[k][0], "read": round(2.0 * gf[k][1] * 1024 / gf[k][0] / 1e9, 4),
+        "write": round(gw.get(k, [1, 0.0])[1] * 1024 / gf[k][0] / 1e9, 4)} for k in sorted(gf)}
 json.dump(res, open(out, "w"), indent=1)
-print(res)
+print({k: v for k, v in res.items() if k != 'by_launch_shape_gb_per_launch'})

@@ -1,16 +1,24 @@
+# usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag> <workload>
+# rocprofv3 kernel stats (serial + shipped mode) and PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy) of one workload;
+# keeps only the small summaries under gpurun_out/<tag>/<workload>/ (copy what is to be judged into profiles/).
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+TAG=$1; WL=$2
+O=$R/gpurun_out/$TAG/$WL
+mkdir -p $O
 cd /tmp
-mkdir -p $R/gpurun_out/r01b
-python3 $R/bench.py --layer-report $R/gpurun_out/r01b/per_launch.csv > $R/gpurun_out/r01b/bench_line.json 2> $R/gpurun_out/r01b/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r01b/serial -o serial -- python3 $R/bench.py --serial --no-cpu-baseline > $R/gpurun_out/r01b/serial_bench_line.json 2> $R/gpurun_out/r01b/serial.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r01b/default -o default -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/r01b/default_bench_line.json 2> $R/gpurun_out/r01b/default.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/r01b/fetch -o fetch -- python3 $R/bench.py --serial --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/r01b/fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/r01b/write -o write -- python3 $R/bench.py --serial --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/r01b/write.err
+COMMON="--workload $WL --no-cpu-baseline --no-also"
+python3 $R/bench.py --workload $WL --no-also --layer-report $O/per_launch.csv > $O/bench_line.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -o serial -- python3 $R/bench.py $COMMON --serial --steps 5 --warmup 2 > $O/serial_bench_line.json 2> $O/serial.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/default -o default -- python3 $R/bench.py $COMMON --steps 5 --warmup 2 > $O/default_bench_line.json 2> $O/default.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python3 $R/bench.py $COMMON --serial --steps 1 --warmup 1 > /dev/null 2> $O/fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python3 $R/bench.py $COMMON --serial --steps 1 --warmup 1 > /dev/null 2> $O/write.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -o mfma -- python3 $R/bench.py $COMMON --serial --steps 1 --warmup 1 > /dev/null 2> $O/mfma.err
 cd $R
-find gpurun_out/r01b -name "*.csv" | head -30
-F=$(find gpurun_out/r01b/fetch -name "*counter_collection.csv" | head -1); W=$(find gpurun_out/r01b/write -name "*counter_collection.csv" | head -1)
-python3 tools/pmc_summary.py $F $W hands_light gpurun_out/r01b/pmc_hands_light.json
-# keep only the small summaries
-find gpurun_out/r01b -name "*kernel_trace.csv" -delete; find gpurun_out/r01b -name "*counter_collection.csv" -delete
-du -sh gpurun_out/r01b
+F=$(find $O/fetch -name "*counter_collection.csv" | head -1); W=$(find $O/write -name "*counter_collection.csv" | head -1)
+python3 tools/pmc_summary.py $F $W $WL $O/pmc_$WL.json
+M=$(find $O/mfma -name "*counter_collection.csv" | head -1)
+python3 tools/pmc_mfma.py $M > $O/pmc_mfma_busy.txt; cat $O/pmc_mfma_busy.txt
+for d in serial default; do S=$(find $O/$d -name "*kernel_stats.csv" | head -1); cp $S $O/${d}_kernel_stats.csv; done
+rm -rf $O/serial $O/default $O/fetch $O/write $O/mfma
+du -sh $O
