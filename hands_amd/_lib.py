@@ -59,6 +59,8 @@ SIGNATURES = {
     "hands_conv2d_nhwc_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P],
     "hands_conv2d_splitk_factor": [C.POINTER(ConvDesc)],
     "hands_conv2d_nhwc_splitk_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_longlong, _P],
+    "hands_conv2d_streamk_grid": [C.POINTER(ConvDesc)],
+    "hands_conv2d_nhwc_streamk_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_longlong, _I, _P],
     "hands_conv1x1_dual_nhwc_f32": [C.POINTER(ConvDesc), _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "hands_conv2d_nhwc_splitk_n_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P, C.c_longlong, _P],
     "hands_stem_conv_maxpool_nhwc_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -107,7 +109,8 @@ SIGNATURES = {
     "hands_pack_conv1x1_dual_f64": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
     "hands_pack_mano_f32": [_P] * 10,
 }
-EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string", "hands_conv2d_workspace_floats")
+EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string", "hands_conv2d_workspace_floats",
+                 "hands_conv2d_streamk_workspace_bytes")
 
 _lib = None
 
@@ -128,6 +131,8 @@ def lib():
         fn.restype = C.c_int
     h.hands_conv2d_workspace_floats.restype = C.c_longlong
     h.hands_conv2d_workspace_floats.argtypes = [C.POINTER(ConvDesc), C.c_int]
+    h.hands_conv2d_streamk_workspace_bytes.restype = C.c_longlong
+    h.hands_conv2d_streamk_workspace_bytes.argtypes = []
     h.hands_abi_version.restype = C.c_int
     h.hands_error_string.restype = C.c_char_p
     h.hands_error_string.argtypes = [C.c_int]

@@ -77,8 +77,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // MODE 0: any convolution with Cin % 16 == 0; 1: the stem (Cin == 4, one filter tap per 16-byte chunk);
 // 2: two 1x1 convolutions summed into one output (k < K0 from `in`, the rest from `in2` sampled with
 //    its own stride) -- the last conv of a bottleneck fused with the block's downsample branch.
+constexpr int SK_SLOT_FLOATS = 4 * 64 * 64;   // one workgroup's accumulators: 4 waves x 64 registers x 64 lanes
+
+// One output tile (BM pixels x BN channels), k-steps [kt0, kt1).  acc_in != nullptr: the accumulators continue a
+// chain another workgroup started (stream-K hand-off, register layout); acc_out != nullptr: dump the raw
+// accumulators there instead of running the epilogue.  `split` is the slice index of the split-K form.
 template <int WAVES_M, int WAVES_N, int MODE>
-__global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int tile, int split, int kt0, int kt1,
+                                          const float* acc_in, float* acc_out) {
   constexpr bool STEM = MODE == 1;
   constexpr bool DUAL = MODE == 2;
   constexpr int BM = 64 * WAVES_M;
@@ -87,7 +93,6 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   constexpr int W_ROWS = BN / 64;   // weight rows staged per thread
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
 
-  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_ROW];
   float* sX = lds;                          // [2][BM][LDS_ROW]
   float* sW = lds + 2 * BM * LDS_ROW;       // [2][BN][LDS_ROW]
 
@@ -97,9 +102,6 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   const int wm = wave / WAVES_N;            // wave row (pixels)
   const int wn = wave % WAVES_N;            // wave col (channels)
 
-  const int ntiles = a.nblk_m * a.nblk_n;
-  const int split = a.ksplit > 1 ? blockIdx.x / ntiles : 0;
-  const int tile = xcd_remap(a.ksplit > 1 ? blockIdx.x - split * ntiles : blockIdx.x, ntiles);
   const int m0 = (tile / a.nblk_n) * BM;    // n fastest: consecutive tiles share the pixel rows
   const int n0 = (tile % a.nblk_n) * BN;
 
@@ -185,23 +187,40 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   } while (0)
 
   f32x16 acc[2][2];
+  if (acc_in != nullptr) {        // continue the FMA chain another workgroup started: same bits as an unsplit tile
+    const float4* src = reinterpret_cast<const float4*>(acc_in) + (wave * 16) * 64 + lane;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = src[((i * 2 + j) * 4 + q) * 64];
+          acc[i][j][q * 4 + 0] = v.x; acc[i][j][q * 4 + 1] = v.y; acc[i][j][q * 4 + 2] = v.z; acc[i][j][q * 4 + 3] = v.w;
+        }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
 
-  // k-step range of this block (the whole K unless split-K) and the running tap state at its start
-  const int nk_all = a.Kpad / BK;
-  const int kt0 = a.ksplit > 1 ? (int)((long long)split * nk_all / a.ksplit) : 0;
-  const int kt1 = a.ksplit > 1 ? (int)((long long)(split + 1) * nk_all / a.ksplit) : nk_all;
+  // running tap / source state at the first k-step of this segment
   if constexpr (MODE == 0) {
-    if (a.ksplit > 1) {
+    if (kt0 > 0) {
       const int tap0 = (kt0 * BK) / a.Cin;
       c0 = kt0 * BK - tap0 * a.Cin;
       kh = tap0 / a.KW;
       kw = tap0 - kh * a.KW;
+    }
+  }
+  if constexpr (DUAL) {
+    if (kt0 * BK > a.K0) {        // segment starts inside the second source
+      dual_src = a.in2 - a.K0;
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) x_base[i] = x_base2[i];
     }
   }
   LOAD_TILES(kt0);
@@ -251,6 +270,18 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   // residual loads and the output stores run 256 B contiguous per pixel row (16 lanes x 16 B) instead
   // of 32 B: the expand convolutions of layer1/layer2 are HBM-bound and store-transaction bound.
   __syncthreads();                                  // every wave is done reading the k-loop tiles
+  if (acc_out != nullptr) {                         // stream-K hand-off: raw accumulators, register layout
+    float4* dst = reinterpret_cast<float4*>(acc_out) + (wave * 16) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          dst[((i * 2 + j) * 4 + q) * 64] =
+              make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+    return;
+  }
   constexpr int EROW = 68;                          // 64 channels + 4 pad floats (17 slots: odd)
   float* sE = lds + wave * (32 * EROW);
   const int half = lane >> 5;
@@ -298,6 +329,91 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
 }
 
 template <int WAVES_M, int WAVES_N, int MODE>
+__global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * (64 * WAVES_M + 64 * WAVES_N) * LDS_ROW];
+  const int ntiles = a.nblk_m * a.nblk_n;
+  const int split = a.ksplit > 1 ? blockIdx.x / ntiles : 0;
+  const int tile = xcd_remap(a.ksplit > 1 ? blockIdx.x - split * ntiles : blockIdx.x, ntiles);
+  // k-step range of this block: the whole K unless split-K
+  const int nk_all = a.Kpad / BK;
+  const int kt0 = a.ksplit > 1 ? (int)((long long)split * nk_all / a.ksplit) : 0;
+  const int kt1 = a.ksplit > 1 ? (int)((long long)(split + 1) * nk_all / a.ksplit) : nk_all;
+  conv_tile<WAVES_M, WAVES_N, MODE>(a, lds, tile, split, kt0, kt1, nullptr, nullptr);
+}
+
+// ---- stream-K: persistent workgroups with equal shares of (tile, k-step) units -------------------------------
+// A launch of T tiles on 256 CUs leaves the CUs that got one tile fewer idle for a tile time (400-1600 tile
+// launches: 76-88 % efficiency).  Here G = 256 * j workgroups (j per CU, G <= T) each take the unit range
+// [g U/G, (g+1) U/G) of the U = T * nk (tile, k-step) units, tiles in the same XCD-aware order.  A range starts in
+// the middle of tile ta (its last k-steps) and ends in the middle of tile tb (its first k-steps):
+//   1. FIRST the head part of tb: k-steps [0, kb), accumulators dumped to this workgroup's slot, flag published;
+//   2. the full tiles in between, each exactly as in the plain kernel;
+//   3. LAST the tail part of ta: its accumulators start from the dump of workgroup g-1 (written at the start of
+//      that workgroup's life, i.e. long ago) and CONTINUE the k-ordered FMA chain, then the normal epilogue.
+// Every output is therefore produced by the same chain of fp32 FMAs as in the plain kernel -- bit-identical,
+// independent of G and of the batch size.  If the flag is not up after a bounded wait (the producer was not
+// resident yet: dispatch order is not guaranteed), the consumer recomputes the head part itself.
+struct SkArgs {
+  float* slots;          // [G][SK_SLOT_FLOATS]
+  int* flags;            // [G], compared against epoch
+  int epoch;             // differs from the previous use of this workspace
+};
+
+template <int WAVES_M, int WAVES_N, int MODE>
+__global__ void __launch_bounds__(256, 2) conv_igemm_sk_f32_kernel(ConvArgs a, SkArgs sk) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * (64 * WAVES_M + 64 * WAVES_N) * LDS_ROW];
+  __shared__ int s_ready;
+  const int G = gridDim.x;
+  const int g = xcd_remap(blockIdx.x, G);
+  const int ntiles = a.nblk_m * a.nblk_n;
+  const int nk = a.Kpad / BK;
+  const long long total = (long long)ntiles * nk;
+  const long long u0 = total * g / G, u1 = total * (g + 1) / G;
+  const int ta = (int)(u0 / nk), ka = (int)(u0 - (long long)ta * nk);
+  const int tb = (int)(u1 / nk), kb = (int)(u1 - (long long)tb * nk);
+
+  const int first_full = ka > 0 ? ta + 1 : ta;
+  const int nfull = tb - first_full;
+  const int head = kb > 0 ? 1 : 0;
+  const int nseg = head + nfull + (ka > 0 ? 1 : 0);
+  for (int sgi = 0; sgi < nseg; ++sgi) {              // one call site: the tile code is instantiated once
+    int tile, k0 = 0, k1 = nk;
+    const float* ain = nullptr;
+    float* aout = nullptr;
+    if (sgi < head) {                                 // 1. head part of the tile the range ends in
+      tile = tb; k1 = kb;
+      aout = sk.slots + (size_t)g * SK_SLOT_FLOATS;
+    } else if (sgi - head < nfull) {                  // 2. full tiles
+      tile = first_full + (sgi - head);
+    } else {                                          // 3. tail part of the tile the range starts in
+      if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int spin = 0; spin < 4096 && !ok; ++spin) {
+          ok = __hip_atomic_load(sk.flags + (g - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sk.epoch;
+          if (!ok) __builtin_amdgcn_s_sleep(8);
+        }
+        if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_ready = ok;
+      }
+      __syncthreads();
+      tile = ta;
+      if (s_ready != 0) { k0 = ka; ain = sk.slots + (size_t)(g - 1) * SK_SLOT_FLOATS; }
+    }
+    __syncthreads();                                  // the staging LDS of the previous segment is free
+    conv_tile<WAVES_M, WAVES_N, MODE>(a, lds, tile, 0, k0, k1, ain, aout);
+    if (aout != nullptr) {                            // publish the dump: release at agent scope, then the flag
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(sk.flags + g, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+template <int WAVES_M, int WAVES_N, int MODE>
 int launch(ConvArgs& a, hipStream_t stream) {
   constexpr int BM = 64 * WAVES_M, BN = 64 * WAVES_N;
   a.nblk_m = (a.M + BM - 1) / BM;
@@ -306,6 +422,69 @@ int launch(ConvArgs& a, hipStream_t stream) {
   if (nwg <= 0 || nwg > 0x7fffffffLL) return HANDS_EINVAL;
   hipLaunchKernelGGL((conv_igemm_f32_kernel<WAVES_M, WAVES_N, MODE>), dim3((unsigned)nwg), dim3(256), 0,
                      stream, a);
+  return (int)hipGetLastError();
+}
+
+constexpr int SK_MAX_G = 1024;
+
+// device facts the stream-K policy needs (immutable properties, looked up once per process)
+int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cus = n;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+
+template <int WAVES_M, int WAVES_N, int MODE>
+int sk_blocks_per_cu() {
+  static int occ = 0;
+  if (occ == 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_igemm_sk_f32_kernel<WAVES_M, WAVES_N, MODE>, 256, 0) != hipSuccess || n < 1)
+      n = 1;
+    occ = n > 4 ? 4 : n;
+  }
+  return occ;
+}
+
+// Persistent grid size for a launch of `ntiles` tiles x `nk` k-steps, or 0 when the plain launch is at least as good:
+// stream-K pays one 64 KB accumulator hand-off per workgroup, so it is taken only when the plain launch would
+// leave > 5 % of the chip idle (tile quantisation: 2-8 tiles per CU) and a tile is long enough (>= 16 k-steps).
+int streamk_grid(long long ntiles, int nk, int cus, int max_per_cu) {
+  // measured (profiles/README.md): 784- and 1568-tile launches gain 8-22 %; short-K pointwise layers with thousands
+  // of tiles lose (the hand-off is a fixed 64 KB write + read per workgroup)
+  if (nk < 16 || ntiles < 2LL * cus || ntiles > 8LL * cus) return 0;
+  const double per_cu = (double)ntiles / cus;
+  const long long rounds = (ntiles + cus - 1) / cus;
+  if (per_cu / (double)rounds > 0.95) return 0;
+  long long j = ntiles / cus;                       // G <= T: every range holds at least one whole tile of work
+  if (j > max_per_cu) j = max_per_cu;
+  long long G = j * cus;
+  if (G > SK_MAX_G) G = SK_MAX_G / cus * cus;
+  return G >= cus ? (int)G : 0;
+}
+
+template <int WAVES_M, int WAVES_N, int MODE>
+int launch_streamk(ConvArgs& a, hipStream_t stream, void* workspace, long long workspace_bytes, int epoch) {
+  constexpr int BM = 64 * WAVES_M, BN = 64 * WAVES_N;
+  a.nblk_m = (a.M + BM - 1) / BM;
+  a.nblk_n = (a.N + BN - 1) / BN;
+  const long long ntiles = (long long)a.nblk_m * a.nblk_n;
+  const int G = (workspace && epoch != 0 && a.ksplit <= 1)
+                    ? streamk_grid(ntiles, a.Kpad / BK, device_cus(), sk_blocks_per_cu<WAVES_M, WAVES_N, MODE>()) : 0;
+  const long long need = (long long)G * SK_SLOT_FLOATS * 4 + (long long)SK_MAX_G * 4;
+  if (G == 0 || workspace_bytes < need) return launch<WAVES_M, WAVES_N, MODE>(a, stream);
+  SkArgs sk;
+  sk.flags = reinterpret_cast<int*>(workspace);                       // [SK_MAX_G] ints first, then the slots
+  sk.slots = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + SK_MAX_G * 4);
+  sk.epoch = epoch;
+  hipLaunchKernelGGL((conv_igemm_sk_f32_kernel<WAVES_M, WAVES_N, MODE>), dim3((unsigned)G), dim3(256), 0, stream, a, sk);
   return (int)hipGetLastError();
 }
 
@@ -402,6 +581,41 @@ extern "C" int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, 
   // point out of reach: no tap state and no bounds checks in the k-loop
   if (pointwise_route_ok(d)) return (d->Cout <= 64) ? launch<4, 1, 2>(a, s) : launch<2, 2, 2>(a, s);
   return (d->Cout <= 64) ? launch<4, 1, 0>(a, s) : launch<2, 2, 0>(a, s);
+}
+
+extern "C" long long hands_conv2d_streamk_workspace_bytes(void) {
+  return (long long)SK_MAX_G * SK_SLOT_FLOATS * 4 + (long long)SK_MAX_G * 4;
+}
+
+extern "C" int hands_conv2d_streamk_grid(const hands_conv_desc* d) {
+  if (!d || !conv_geometry_ok(d) || d->Cin == 4) return 0;
+  const bool narrow = d->Cout <= 64;
+  const long long M = (long long)d->B * d->Ho * d->Wo;
+  const long long ntiles = narrow ? ((M + 255) / 256) * ((d->Cout + 63) / 64) : ((M + 127) / 128) * ((d->Cout + 127) / 128);
+  return streamk_grid(ntiles, d->Kpad / BK, device_cus(), 4);
+}
+
+extern "C" int hands_conv2d_nhwc_streamk_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
+                                             const float* bias, const float* residual, float* out, void* workspace,
+                                             long long workspace_bytes, int epoch, hands_stream_t stream) {
+  if (!d || !in || !w_packed || !bias || !out) return HANDS_EINVAL;
+  if (!conv_geometry_ok(d)) return HANDS_EINVAL;
+  if (d->Cin == 4) return hands_conv2d_nhwc_f32(d, in, w_packed, bias, residual, out, stream);   // the stem has its own kernel
+  ConvArgs a;
+  a.in = in; a.w = w_packed; a.bias = bias; a.res = residual; a.out = out;
+  a.M = d->B * d->Ho * d->Wo; a.N = d->Cout; a.Kpad = d->Kpad;
+  a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+  a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
+  a.relu = d->act;
+  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0;
+  a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (pointwise_route_ok(d))
+    return (d->Cout <= 64) ? launch_streamk<4, 1, 2>(a, s, workspace, workspace_bytes, epoch)
+                           : launch_streamk<2, 2, 2>(a, s, workspace, workspace_bytes, epoch);
+  return (d->Cout <= 64) ? launch_streamk<4, 1, 0>(a, s, workspace, workspace_bytes, epoch)
+                         : launch_streamk<2, 2, 0>(a, s, workspace, workspace_bytes, epoch);
 }
 
 extern "C" int hands_conv1x1_dual_nhwc_f32(const hands_conv_desc* d, const float* in, const float* in2, int Cin2, int H2,

@@ -226,7 +226,7 @@ struct ManoHeadsArgs {
   float img_res, min_s;
 };
 
-constexpr int MH = 16;             // hands per block = MFMA N
+constexpr int MH = 16;             // hands per block = MFMA N tiles of 16 (32 measured no faster: the kernel is MFMA-bound)
 constexpr int CHUNK_V = 64;        // vertices per chunk
 constexpr int CHUNK_M = 192;       // blend outputs per chunk = 12 row tiles of 16
 constexpr int NCHUNK = (NV + CHUNK_V - 1) / CHUNK_V;   // 13
@@ -239,12 +239,10 @@ template <bool AA_INPUT>
 __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
   // phase-1 scratch (joint rotations, rest joints, global transforms) is dead once A is built: it shares its
   // bytes with the v_posed stage of phases 2-3
-  __shared__ __attribute__((aligned(16))) float sScratch[2 * MH * VROW];
-  static_assert(MH * NJ * (9 + 3 + 12) <= 2 * MH * VROW, "phase-1 scratch must fit in the stage buffers");
-  float (*sR)[NJ][9] = reinterpret_cast<float (*)[NJ][9]>(sScratch);
-  float (*sJ)[NJ][3] = reinterpret_cast<float (*)[NJ][3]>(sScratch + MH * NJ * 9);
-  float (*sG)[NJ][12] = reinterpret_cast<float (*)[NJ][12]>(sScratch + MH * NJ * 12);
-  float (*sV)[MH][VROW] = reinterpret_cast<float (*)[MH][VROW]>(sScratch);
+  __shared__ __attribute__((aligned(16))) float sScratch[MH * NJ * 15 > MH * VROW ? MH * NJ * 15 : MH * VROW];
+  float (*sJ)[NJ][3] = reinterpret_cast<float (*)[NJ][3]>(sScratch);
+  float (*sG)[NJ][12] = reinterpret_cast<float (*)[NJ][12]>(sScratch + MH * NJ * 3);
+  float (*stage)[VROW] = reinterpret_cast<float (*)[VROW]>(sScratch);
   __shared__ float sA[MH][NJ * 12];
   __shared__ __attribute__((aligned(16))) float sBin[MH][BROW];
   __shared__ float sCam[MH][3];
@@ -255,118 +253,132 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
   const int b0 = blockIdx.x * MH;
   const int B = a.B;
 
-  // ---- phase 1: pose, joints, forward kinematics (one thread per hand-joint) ------------------------------
+  // ---- phase 1: pose, joints, forward kinematics: thread = (hand h or h + 16, joint j) ----------------------
   {
-    const int h = tid >> 4, j = tid & 15;
-    const int b = b0 + h;
-    const bool live = b < B;
-    if (live) {
-      float aa[3], R[9];
-      if constexpr (AA_INPUT) {
-        const float* src = S.rot + ((long long)b * NJ + j) * 3;
-        aa[0] = src[0]; aa[1] = src[1]; aa[2] = src[2];
+    const int j = tid & 15;
+    float Rloc[MH / 16][9];                          // this thread's local joint rotations (one per hand it owns)
+#pragma unroll
+    for (int rep = 0; rep < MH / 16; ++rep) {
+      const int h = (tid >> 4) + 16 * rep;
+      const int b = b0 + h;
+      if (b < B) {
+        float aa[3];
+        float* R = Rloc[rep];
+        if constexpr (AA_INPUT) {
+          const float* src = S.rot + ((long long)b * NJ + j) * 3;
+          aa[0] = src[0]; aa[1] = src[1]; aa[2] = src[2];
+        } else {
+          hands::matrix_to_axis_angle(S.rot + ((long long)b * NJ + j) * 9, aa);
+        }
+        aa[0] += c.pose_mean[3 * j + 0];
+        aa[1] += c.pose_mean[3 * j + 1];
+        aa[2] += c.pose_mean[3 * j + 2];
+        hands::rodrigues(aa, R);
+        const float* be = S.betas + (long long)b * a.ld_betas;
+        float* row = sBin[h];
+        if (j >= 1) {
+#pragma unroll
+          for (int e = 0; e < 9; ++e) row[10 + (j - 1) * 9 + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+        }
+        if (j < 10) row[j] = be[j];
+        if (j < 15) row[145 + j] = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          float acc = c.J_template[3 * j + cc];
+          const float* js = c.J_shapedirs + (3 * j + cc) * 10;
+#pragma unroll
+          for (int k = 0; k < 10; ++k) acc += js[k] * be[k];
+          sJ[h][j][cc] = acc;
+        }
+        if (j == 0) {
+          // weak_perspective_to_perspective_torch (camera.py:456-474) with focal = (K00 + K11)/2
+          const float* Kb = a.K + (long long)b * 9;
+          const float f = (Kb[0] + Kb[4]) / 2.0f;
+          const float s = fmaxf(S.cam_wp[b * 3 + 0], a.min_s);
+          sCam[h][0] = S.cam_wp[b * 3 + 1];
+          sCam[h][1] = S.cam_wp[b * 3 + 2];
+          sCam[h][2] = 2.0f * f / (a.img_res * s + 1e-9f);
+        }
       } else {
-        hands::matrix_to_axis_angle(S.rot + ((long long)b * NJ + j) * 9, aa);
+        for (int e = j; e < 160; e += NJ) sBin[h][e] = 0.f;   // dead rows feed zeros to the matrix cores
       }
-      aa[0] += c.pose_mean[3 * j + 0];
-      aa[1] += c.pose_mean[3 * j + 1];
-      aa[2] += c.pose_mean[3 * j + 2];
-      hands::rodrigues(aa, R);
-#pragma unroll
-      for (int e = 0; e < 9; ++e) sR[h][j][e] = R[e];
-      const float* be = S.betas + (long long)b * a.ld_betas;
-      float* row = sBin[h];
-      if (j >= 1) {
-#pragma unroll
-        for (int e = 0; e < 9; ++e) row[10 + (j - 1) * 9 + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
-      }
-      if (j < 10) row[j] = be[j];
-      if (j < 15) row[145 + j] = 0.f;
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc) {
-        float acc = c.J_template[3 * j + cc];
-        const float* js = c.J_shapedirs + (3 * j + cc) * 10;
-#pragma unroll
-        for (int k = 0; k < 10; ++k) acc += js[k] * be[k];
-        sJ[h][j][cc] = acc;
-      }
-      if (j == 0) {
-        // weak_perspective_to_perspective_torch (camera.py:456-474) with focal = (K00 + K11)/2
-        const float* Kb = a.K + (long long)b * 9;
-        const float f = (Kb[0] + Kb[4]) / 2.0f;
-        const float s = fmaxf(S.cam_wp[b * 3 + 0], a.min_s);
-        sCam[h][0] = S.cam_wp[b * 3 + 1];
-        sCam[h][1] = S.cam_wp[b * 3 + 2];
-        sCam[h][2] = 2.0f * f / (a.img_res * s + 1e-9f);
-      }
-    } else {
-      for (int e = j; e < 160; e += NJ) sBin[h][e] = 0.f;   // dead rows feed zeros to the matrix cores
     }
     __syncthreads();
     const int dj = depth_of(j), pj = parent_of(j);
     for (int level = 0; level < 4; ++level) {
-      if (live && dj == level) {
-        float* g = sG[h][j];
-        const float* r = sR[h][j];
-        if (level == 0) {
 #pragma unroll
-          for (int rr = 0; rr < 3; ++rr) {
-            g[rr * 4 + 0] = r[rr * 3 + 0]; g[rr * 4 + 1] = r[rr * 3 + 1]; g[rr * 4 + 2] = r[rr * 3 + 2];
-            g[rr * 4 + 3] = sJ[h][0][rr];
-          }
-        } else {
-          const float* gp = sG[h][pj];
-          const float t0 = sJ[h][j][0] - sJ[h][pj][0], t1 = sJ[h][j][1] - sJ[h][pj][1],
-                      t2 = sJ[h][j][2] - sJ[h][pj][2];
+      for (int rep = 0; rep < MH / 16; ++rep) {
+        const int h = (tid >> 4) + 16 * rep;
+        if (b0 + h < B && dj == level) {
+          float* g = sG[h][j];
+          const float* r = Rloc[rep];
+          if (level == 0) {
 #pragma unroll
-          for (int rr = 0; rr < 3; ++rr) {
-            const float p0 = gp[rr * 4 + 0], p1 = gp[rr * 4 + 1], p2 = gp[rr * 4 + 2], p3 = gp[rr * 4 + 3];
-            g[rr * 4 + 0] = p0 * r[0] + p1 * r[3] + p2 * r[6];
-            g[rr * 4 + 1] = p0 * r[1] + p1 * r[4] + p2 * r[7];
-            g[rr * 4 + 2] = p0 * r[2] + p1 * r[5] + p2 * r[8];
-            g[rr * 4 + 3] = p0 * t0 + p1 * t1 + p2 * t2 + p3;
+            for (int rr = 0; rr < 3; ++rr) {
+              g[rr * 4 + 0] = r[rr * 3 + 0]; g[rr * 4 + 1] = r[rr * 3 + 1]; g[rr * 4 + 2] = r[rr * 3 + 2];
+              g[rr * 4 + 3] = sJ[h][0][rr];
+            }
+          } else {
+            const float* gp = sG[h][pj];
+            const float t0 = sJ[h][j][0] - sJ[h][pj][0], t1 = sJ[h][j][1] - sJ[h][pj][1],
+                        t2 = sJ[h][j][2] - sJ[h][pj][2];
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {
+              const float p0 = gp[rr * 4 + 0], p1 = gp[rr * 4 + 1], p2 = gp[rr * 4 + 2], p3 = gp[rr * 4 + 3];
+              g[rr * 4 + 0] = p0 * r[0] + p1 * r[3] + p2 * r[6];
+              g[rr * 4 + 1] = p0 * r[1] + p1 * r[4] + p2 * r[7];
+              g[rr * 4 + 2] = p0 * r[2] + p1 * r[5] + p2 * r[8];
+              g[rr * 4 + 3] = p0 * t0 + p1 * t1 + p2 * t2 + p3;
+            }
           }
         }
       }
       __syncthreads();
     }
-    if (live) {
-      const float* g = sG[h][j];
-      float* am = sA[h] + j * 12;
-      const float j0 = sJ[h][j][0], j1 = sJ[h][j][1], j2 = sJ[h][j][2];
-      const float cx = sCam[h][0], cy = sCam[h][1], cz = sCam[h][2];
-      float p[3];
 #pragma unroll
-      for (int rr = 0; rr < 3; ++rr) {
-        am[rr * 4 + 0] = g[rr * 4 + 0]; am[rr * 4 + 1] = g[rr * 4 + 1]; am[rr * 4 + 2] = g[rr * 4 + 2];
-        am[rr * 4 + 3] = g[rr * 4 + 3] - (g[rr * 4 + 0] * j0 + g[rr * 4 + 1] * j1 + g[rr * 4 + 2] * j2);
-        p[rr] = g[rr * 4 + 3];
-      }
-      if (blockIdx.z == 0) {       // the 16 posed joints + camera outputs: written by the first vertex-range block
-        float* dj3 = S.o.joints3d + ((long long)b * 21 + j) * 3;
-        dj3[0] = p[0]; dj3[1] = p[1]; dj3[2] = p[2];
-        const float px = p[0] + cx, py = p[1] + cy, pz = p[2] + cz;
-        float* dc = S.o.j3d_cam + ((long long)b * 21 + j) * 3;
-        dc[0] = px; dc[1] = py; dc[2] = pz;
-        const float* Kb = a.K + (long long)b * 9;
-        const float hx = Kb[0] * px + Kb[1] * py + Kb[2] * pz;
-        const float hy = Kb[3] * px + Kb[4] * py + Kb[5] * pz;
-        const float hz = Kb[6] * px + Kb[7] * py + Kb[8] * pz;
-        float* d2 = S.o.j2d_norm + ((long long)b * 21 + j) * 2;
-        d2[0] = 2.0f * (hx / hz) / a.img_res - 1.0f;
-        d2[1] = 2.0f * (hy / hz) / a.img_res - 1.0f;
-        if (j < 3) S.o.cam_t[b * 3 + j] = sCam[h][j];
+    for (int rep = 0; rep < MH / 16; ++rep) {
+      const int h = (tid >> 4) + 16 * rep;
+      const int b = b0 + h;
+      if (b < B) {
+        const float* g = sG[h][j];
+        float* am = sA[h] + j * 12;
+        const float j0 = sJ[h][j][0], j1 = sJ[h][j][1], j2 = sJ[h][j][2];
+        const float cx = sCam[h][0], cy = sCam[h][1], cz = sCam[h][2];
+        float p[3];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          am[rr * 4 + 0] = g[rr * 4 + 0]; am[rr * 4 + 1] = g[rr * 4 + 1]; am[rr * 4 + 2] = g[rr * 4 + 2];
+          am[rr * 4 + 3] = g[rr * 4 + 3] - (g[rr * 4 + 0] * j0 + g[rr * 4 + 1] * j1 + g[rr * 4 + 2] * j2);
+          p[rr] = g[rr * 4 + 3];
+        }
+        if (blockIdx.z == 0) {       // the 16 posed joints + camera outputs: written by the first vertex-range block
+          float* dj3 = S.o.joints3d + ((long long)b * 21 + j) * 3;
+          dj3[0] = p[0]; dj3[1] = p[1]; dj3[2] = p[2];
+          const float px = p[0] + cx, py = p[1] + cy, pz = p[2] + cz;
+          float* dc = S.o.j3d_cam + ((long long)b * 21 + j) * 3;
+          dc[0] = px; dc[1] = py; dc[2] = pz;
+          const float* Kb = a.K + (long long)b * 9;
+          const float hx = Kb[0] * px + Kb[1] * py + Kb[2] * pz;
+          const float hy = Kb[3] * px + Kb[4] * py + Kb[5] * pz;
+          const float hz = Kb[6] * px + Kb[7] * py + Kb[8] * pz;
+          float* d2 = S.o.j2d_norm + ((long long)b * 21 + j) * 2;
+          d2[0] = 2.0f * (hx / hz) / a.img_res - 1.0f;
+          d2[1] = 2.0f * (hy / hz) / a.img_res - 1.0f;
+          if (j < 3) S.o.cam_t[b * 3 + j] = sCam[h][j];
+        }
       }
     }
-    __syncthreads();
+    __syncthreads();      // sA complete; the scratch (sR, sJ, sG) is free for the v_posed stage from here on
   }
 
   // ---- phase 2 + 3 per chunk --------------------------------------------------------------------------------
   const int lane = tid & 63, wave = tid >> 6;
-  const int mh = lane & 15, g = lane >> 4;           // MFMA column (hand) and k-group
-  float4 bfrag[10];                                  // this lane's blend-input operand: k = 16*s + 4*g + e
+  const int mh = lane & 15, g = lane >> 4;           // MFMA column (hand within a 16-hand group) and k-group
+  float4 bfrag[MH / 16][10];                         // this lane's blend-input operands: k = 16*s + 4*g + e
 #pragma unroll
-  for (int s4 = 0; s4 < 10; ++s4) bfrag[s4] = *reinterpret_cast<const float4*>(&sBin[mh][16 * s4 + 4 * g]);
+  for (int nt = 0; nt < MH / 16; ++nt)
+#pragma unroll
+    for (int s4 = 0; s4 < 10; ++s4) bfrag[nt][s4] = *reinterpret_cast<const float4*>(&sBin[nt * 16 + mh][16 * s4 + 4 * g]);
 
   const int c0 = (int)((long long)blockIdx.z * NCHUNK / a.vsplit);
   const int c1 = (int)((long long)(blockIdx.z + 1) * NCHUNK / a.vsplit);
@@ -378,38 +390,52 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
   const int e12 = lane & 15;                         // MFMA row of the transform GEMM: entry e of A_u (12 used)
 
   for (int ch = c0; ch < c1; ++ch) {
-    float (*stage)[VROW] = sV[(ch - c0) & 1];
-    // -- blend GEMM of this chunk: wave w owns row tiles w, w+4, w+8; the three accumulation chains are
-    //    independent, so their MFMAs are issued round-robin (issue-bound instead of latency-bound) after all
-    //    thirty weight fragments have been requested
+    // -- blend GEMM of this chunk: wave w owns row tiles w, w+4, w+8.  A weight fragment (16 rows x 4 k per
+    //    instruction, straight from L2 in operand order) feeds one MFMA per 16-hand group, so the 1.5 MB blend
+    //    matrix is streamed once per MH hands; the groups' accumulation chains are independent and interleaved
+    float4 wf[10];
     {
-      float4 wf[3][10];
-      f32x4 acc[3];
+      int m0 = ch * CHUNK_M + wave * 16;
+      m0 = m0 < 2432 ? m0 : 2432 - 16;                 // past the packed matrix: recompute its (all-zero) last tile
+      const float* wr = S.blend_w + (size_t)(m0 + mh) * 160 + 4 * g;
 #pragma unroll
-      for (int tt = 0; tt < 3; ++tt) {
-        int m0 = ch * CHUNK_M + (wave + 4 * tt) * 16;
-        m0 = m0 < 2432 ? m0 : 2432 - 16;               // past the packed matrix: recompute its (all-zero) last tile
-        const float* wr = S.blend_w + (size_t)(m0 + mh) * 160 + 4 * g;
+      for (int s4 = 0; s4 < 10; ++s4) wf[s4] = *reinterpret_cast<const float4*>(wr + 16 * s4);
+    }
 #pragma unroll
-        for (int s4 = 0; s4 < 10; ++s4) wf[tt][s4] = *reinterpret_cast<const float4*>(wr + 16 * s4);
-        const float4 bias = *reinterpret_cast<const float4*>(S.blend_bias + m0 + 4 * g);
-        acc[tt][0] = bias.x; acc[tt][1] = bias.y; acc[tt][2] = bias.z; acc[tt][3] = bias.w;
+    for (int tt = 0; tt < 3; ++tt) {
+      int m0 = ch * CHUNK_M + (wave + 4 * tt) * 16;
+      m0 = m0 < 2432 ? m0 : 2432 - 16;
+      const float4 bias = *reinterpret_cast<const float4*>(S.blend_bias + m0 + 4 * g);
+      f32x4 acc[MH / 16];
+#pragma unroll
+      for (int nt = 0; nt < MH / 16; ++nt) { acc[nt][0] = bias.x; acc[nt][1] = bias.y; acc[nt][2] = bias.z; acc[nt][3] = bias.w; }
+      float4 wn[10];                                   // next tile's fragments, requested under this tile's MFMAs
+      if (tt < 2) {
+        int m1 = ch * CHUNK_M + (wave + 4 * (tt + 1)) * 16;
+        m1 = m1 < 2432 ? m1 : 2432 - 16;
+        const float* wr = S.blend_w + (size_t)(m1 + mh) * 160 + 4 * g;
+#pragma unroll
+        for (int s4 = 0; s4 < 10; ++s4) wn[s4] = *reinterpret_cast<const float4*>(wr + 16 * s4);
       }
 #pragma unroll
       for (int s4 = 0; s4 < 10; ++s4) {
 #pragma unroll
-        for (int tt = 0; tt < 3; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tt][s4].x, bfrag[s4].x, acc[tt], 0, 0, 0);
+        for (int nt = 0; nt < MH / 16; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s4].x, bfrag[nt][s4].x, acc[nt], 0, 0, 0);
 #pragma unroll
-        for (int tt = 0; tt < 3; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tt][s4].y, bfrag[s4].y, acc[tt], 0, 0, 0);
+        for (int nt = 0; nt < MH / 16; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s4].y, bfrag[nt][s4].y, acc[nt], 0, 0, 0);
 #pragma unroll
-        for (int tt = 0; tt < 3; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tt][s4].z, bfrag[s4].z, acc[tt], 0, 0, 0);
+        for (int nt = 0; nt < MH / 16; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s4].z, bfrag[nt][s4].z, acc[nt], 0, 0, 0);
 #pragma unroll
-        for (int tt = 0; tt < 3; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tt][s4].w, bfrag[s4].w, acc[tt], 0, 0, 0);
+        for (int nt = 0; nt < MH / 16; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s4].w, bfrag[nt][s4].w, acc[nt], 0, 0, 0);
       }
 #pragma unroll
-      for (int tt = 0; tt < 3; ++tt)
-        *reinterpret_cast<float4*>(&stage[mh][(wave + 4 * tt) * 16 + 4 * g]) =
-            make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
+      for (int nt = 0; nt < MH / 16; ++nt)
+        *reinterpret_cast<float4*>(&stage[nt * 16 + mh][(wave + 4 * tt) * 16 + 4 * g]) =
+            make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
+      if (tt < 2) {
+#pragma unroll
+        for (int s4 = 0; s4 < 10; ++s4) wf[s4] = wn[s4];
+      }
     }
     __syncthreads();
     // -- skinning: T[v][h] = sum_u w[v][u] A_h[u] as a (12 x 16 joints) x (16 joints x 16 vertices) product per hand
@@ -453,7 +479,7 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
     // the wave's 16 vertices x 3 coordinates of every hand are 48 consecutive floats both in the stage and in
     // the output arrays: write them back 8 bytes per lane (hand rows are 9336 B apart: 8-byte aligned)
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {
+    for (int it = 0; it < MH * 24 / 64; ++it) {
       const int idx = it * 64 + lane;
       const int h = idx / 24, k2 = (idx - 24 * h) * 2;
       const int m = ch * CHUNK_M + wave * 48 + k2;   // first of the two output floats (vertex-major, 3 per vertex)
@@ -466,10 +492,8 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
             make_float2(o2.x + sCam[h][c0i], o2.y + sCam[h][c1i]);
       }
     }
-    // the next chunk's GEMM writes the other stage buffer; this one is rewritten two chunks later, after the
-    // barrier of the next iteration
+    __syncthreads();      // the stage is rewritten by the next chunk's GEMM
   }
-  __syncthreads();
   // ---- fingertip joints 16..20 of the tips whose vertex this block skinned: joints3d, camera space, projection
   if (tid < MH * 5) {
     const int h = tid / 5, t = tid - 5 * h;
@@ -518,7 +542,7 @@ int hands_mano_heads_f32(const hands_mano_side* sides, int n_sides, const float*
   int vs = 512 / (nb * n_sides);
   vs = vs < 1 ? 1 : (vs > NCHUNK ? NCHUNK : vs);
   a.vsplit = vs;
-  dim3 grid((unsigned)nb, (unsigned)n_sides, (unsigned)vs);
+  dim3 grid((unsigned)nb, (unsigned)n_sides, (unsigned)a.vsplit);
   if (axis_angle_input) hipLaunchKernelGGL(mano_heads_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(mano_heads_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
   HANDS_LAUNCH_CHECK();

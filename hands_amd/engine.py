@@ -25,14 +25,16 @@ class ConvEngine:
         self.overlap = True           # run independent jobs (trunks, heads, crop chunks) on side HIP streams
         self.fuse_stem_pool = True    # stem conv + BN + act + max-pool as one kernel (csrc/stem_pool.hip)
         self.fuse_downsample = True   # first block of a stage: conv3 + downsample + add + ReLU as one two-source GEMM
+        self.stream_k = True          # persistent stream-K launches where the tile count quantises badly (bit-identical)
         self.fuse_mano = True         # MANOHead.forward of both hands as one launch (hands_mano_heads_f32)
         self.hook = None              # callable(phase, pc, npix, stream_handle, has_res, kernel): bench.py brackets
                                       # every MFMA launch (conv_igemm and the fused stem) with events
         self._splitk_ws = {}          # (device, stream handle) -> workspace tensor
+        self._sk_ws = {}              # (device, stream handle) -> [zeroed stream-K workspace, epoch counter]
 
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
-        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "fuse_mano"):
+        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "fuse_mano", "stream_k"):
             setattr(e, k, getattr(self, k))
         return e
 
@@ -77,6 +79,18 @@ class ConvEngine:
             check(L.hands_conv2d_nhwc_splitk_n_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
                                                    ptr(res, res_off) if res is not None else None, ptr(out, out_off),
                                                    S, ptr(ws), ws.numel(), stream), "hands_conv2d_nhwc_splitk_n_f32")
+        elif self.stream_k and L.hands_conv2d_streamk_grid(C.byref(d)) > 0:
+            key = (x.device, stream)
+            sk = self._sk_ws.get(key)
+            if sk is None:
+                nbytes = L.hands_conv2d_streamk_workspace_bytes()
+                sk = self._sk_ws[key] = [torch.zeros(nbytes // 4, dtype=torch.int32, device=x.device), 0]
+                torch.cuda.current_stream(x.device).synchronize()     # zero-fill done before a side stream uses it
+            sk[1] = sk[1] % 0x7FFFFFF0 + 1
+            check(L.hands_conv2d_nhwc_streamk_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
+                                                  ptr(res, res_off) if res is not None else None, ptr(out, out_off),
+                                                  ptr(sk[0]), sk[0].numel() * 4, sk[1], stream),
+                  "hands_conv2d_nhwc_streamk_f32")
         else:
             check(L.hands_conv2d_nhwc_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
                                           ptr(res, res_off) if res is not None else None, ptr(out, out_off),
@@ -85,7 +99,7 @@ class ConvEngine:
             hook("end", pc, B * Ho * Wo, stream, res is not None, "conv_igemm_f32_kernel")
         return Ho, Wo
 
-    def conv_dual(self, L, pc, split, x, x2, B, Ho, Wo, H2, W2, out, stream, act=1):
+    def conv_dual(self, L, pc, split, x, x2, B, Ho, Wo, H2, W2, out, stream, act=1, out_off=0):
         """act(conv3(x) + downsample(x2)) (resnet.py:146-154) with the identity never materialised."""
         K0, K1, stride2 = split
         d = ConvDesc(B, Ho, Wo, K0, Ho, Wo, pc.Cout, 1, 1, 1, 0, K0, pc.Cout, 0, pc.Kpad, int(act))
@@ -93,7 +107,7 @@ class ConvEngine:
         if hook is not None:
             hook("begin", pc, B * Ho * Wo, stream, False, "conv_igemm_f32_kernel")
         check(L.hands_conv1x1_dual_nhwc_f32(C.byref(d), ptr(x), ptr(x2), K1, H2, W2, stride2, K1, ptr(pc.w), ptr(pc.bias),
-                                            ptr(out), stream), "hands_conv1x1_dual_nhwc_f32")
+                                            ptr(out, out_off), stream), "hands_conv1x1_dual_nhwc_f32")
         if hook is not None:
             hook("end", pc, B * Ho * Wo, stream, False, "conv_igemm_f32_kernel")
 

@@ -123,11 +123,22 @@ def run_mano_heads(L, mano_r, mano_l, rot, shape, cam, cam_init, K, img_res, bz,
     engine = engine or DEFAULT_ENGINE
     fused = getattr(engine, "fuse_mano", True)
     output = xdict()
+    # the twelve output tensors are contiguous views of ONE allocation (one allocator call per forward); the
+    # two vertex arrays come first in each side's 16-byte aligned block (the kernel stores them 8 bytes wide)
+    shapes = (("vertices", (778, 3)), ("v3d.cam", (778, 3)), ("joints3d", (21, 3)), ("j3d.cam", (21, 3)),
+              ("j2d.norm", (21, 2)), ("cam_t", (3,)))
+    side_floats = (bz * 4839 + 3) // 4 * 4
+    flat = torch.empty(2 * side_floats, device=dev)
     outs = []
     for side in range(2):
-        outs.append({"vertices": torch.empty(bz, 778, 3, device=dev), "joints3d": torch.empty(bz, 21, 3, device=dev),
-                     "v3d.cam": torch.empty(bz, 778, 3, device=dev), "j3d.cam": torch.empty(bz, 21, 3, device=dev),
-                     "j2d.norm": torch.empty(bz, 21, 2, device=dev), "cam_t": torch.empty(bz, 3, device=dev)})
+        o, off = {}, side * side_floats
+        for name, shp in shapes:
+            n = bz
+            for d_ in shp:
+                n *= d_
+            o[name] = flat[off:off + n].view((bz,) + shp)
+            off += n
+        outs.append(o)
     mouts = [ManoOut(ptr(o["vertices"]), ptr(o["joints3d"]), ptr(o["v3d.cam"]), ptr(o["j3d.cam"]),
                      ptr(o["j2d.norm"]), ptr(o["cam_t"])) for o in outs]
     if fused:
@@ -387,44 +398,49 @@ class HandsLight(EngineSwitches, nn.Module):
     _conv = staticmethod(lambda *a, **kw: DEFAULT_ENGINE.conv(*a, **kw))
     _conv_dual = staticmethod(lambda *a, **kw: DEFAULT_ENGINE.conv_dual(*a, **kw))
 
-    def _trunk(self, L, P, x4, B, res_in, stream, tag, cap_B, out=None, x_off=0, out_off=0):
-        """ResNet-50 trunk on an NHWC4 batch; returns (B,7,7,2048) features (flat tensor)."""
-        dev = x4.device
-        H = W = res_in
-        per = 112 * 112 * 64 * (res_in * res_in) // (224 * 224) + 64
-        cap = cap_B * per
-        a = self._buf("trunk_a_" + tag, cap, dev); b = self._buf("trunk_b_" + tag, cap, dev)
-        t1 = self._buf("trunk_t1_" + tag, cap, dev); t2 = self._buf("trunk_t2_" + tag, cap, dev)
-        ds = self._buf("trunk_ds_" + tag, cap, dev)
-        if self.engine.fuse_stem_pool:
-            # conv1 + bn1 + relu + maxpool in one kernel: the 112x112x64 map never reaches HBM
-            Ho, Wo = self.engine.stem_pool(L, P["stem"], x4, x_off, b, B, H, W, 1, stream)
-        else:
-            Ho, Wo = self.engine.conv(L, P["stem"], x4, B, H, W, a, True, stream, x_off=x_off)
-            check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(b), B, Ho, Wo, 64, stream), "maxpool")
-        H, W = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
-        cur, nxt = b, a
-        nblk = len(P["blocks"])
-        for i, e in enumerate(P["blocks"]):
+    def _blocks(self, L, blocks, cur, nxt, t1, t2, ds, B, H, W, stream, final_dst, final_off):
+        """A run of bottlenecks (resnet.py:134-154) on ping-pong buffers; the last one writes ``final_dst``
+        at float offset ``final_off``.  Returns (H, W) of the output map."""
+        n = len(blocks)
+        for i, e in enumerate(blocks):
             self.engine.conv(L, e["c1"], cur, B, H, W, t1, True, stream)
             H2, W2 = self.engine.conv(L, e["c2"], t1, B, H, W, t2, True, stream)
-            last = i + 1 == nblk
-            dst = nxt if not last else (out if out is not None else
-                                        self._buf("feat_" + tag, B * H2 * W2 * e["c3"].Cout, dev))
+            last = i + 1 == n
+            dst, off = (final_dst, final_off) if last else (nxt, 0)
             if "ds" in e and self.engine.fuse_downsample:
-                self.engine.conv_dual(L, e["c3ds"], e["c3ds_split"], t2, cur, B, H2, W2, H, W, dst, stream)
+                self.engine.conv_dual(L, e["c3ds"], e["c3ds_split"], t2, cur, B, H2, W2, H, W, dst, stream, out_off=off)
             else:
                 if "ds" in e:
                     self.engine.conv(L, e["ds"], cur, B, H, W, ds, False, stream)
                     ident = ds
                 else:
                     ident = cur
-                self.engine.conv(L, e["c3"], t2, B, H2, W2, dst, True, stream, res=ident, out_off=out_off if last else 0)
+                self.engine.conv(L, e["c3"], t2, B, H2, W2, dst, True, stream, res=ident, out_off=off)
             H, W = H2, W2
             cur, nxt = dst, cur
-            if i + 1 == nblk:
-                return dst, H, W
-        raise AssertionError
+        return H, W
+
+    def _trunk(self, L, P, x4, B, res_in, stream, tag, cap_B, out=None, x_off=0, out_off=0):
+        """ResNet-50 trunk on an NHWC4 batch; returns (B,7,7,2048) features (flat tensor).
+        (Running stem + layer1 + layer2 per sub-batch of 32-128 images, to keep their HBM-bound 1x1 layers'
+        tensors inside the 256 MB Infinity Cache, was measured 1-18 % SLOWER than whole-job launches.)"""
+        dev = x4.device
+        per = 112 * 112 * 64 * (res_in * res_in) // (224 * 224) + 64      # floats per image of the largest map
+        cap = cap_B * per
+        a = self._buf("trunk_a_" + tag, cap, dev); b = self._buf("trunk_b_" + tag, cap, dev)
+        t1 = self._buf("trunk_t1_" + tag, cap, dev); t2 = self._buf("trunk_t2_" + tag, cap, dev)
+        ds = self._buf("trunk_ds_" + tag, cap, dev)
+        Hs, Ws = (res_in - 1) // 2 + 1, (res_in - 1) // 2 + 1                # stem conv map
+        Hp, Wp = (Hs + 2 - 3) // 2 + 1, (Ws + 2 - 3) // 2 + 1                # after the max-pool
+        if self.engine.fuse_stem_pool:
+            # conv1 + bn1 + relu + maxpool in one kernel: the 112x112x64 map never reaches HBM
+            self.engine.stem_pool(L, P["stem"], x4, x_off, b, B, res_in, res_in, 1, stream)
+        else:
+            self.engine.conv(L, P["stem"], x4, B, res_in, res_in, a, True, stream, x_off=x_off)
+            check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(b), B, Hs, Ws, 64, stream), "maxpool")
+        feat = out if out is not None else self._buf("feat_" + tag, B * 49 * P["blocks"][-1]["c3"].Cout, dev)
+        H, W = self._blocks(L, P["blocks"], b, a, t1, t2, ds, B, Hp, Wp, stream, feat, out_off)
+        return feat, H, W
 
     # ---- forward ------------------------------------------------------------------------------
     @torch.no_grad()

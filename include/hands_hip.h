@@ -87,6 +87,21 @@ int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const float* in, co
                                    const float* bias, const float* residual, float* out, int S,
                                    float* workspace, long long workspace_floats, hands_stream_t stream);
 
+/* Stream-K form of hands_conv2d_nhwc_f32 for launches whose tile count quantises badly on the chip (400-1600
+ * tiles on 256 CUs leave 12-24 % of it idle): G persistent workgroups take equal shares of the (tile, k-step)
+ * units; a tile cut between two workgroups is finished by the second one CONTINUING the first one's fp32 FMA chain
+ * from its dumped accumulators, so every output bit equals the plain launch (and stays independent of the batch
+ * size).  hands_conv2d_streamk_grid() returns G, or 0 when the library would take the plain launch (short K, few
+ * or very many tiles, < 5 % to gain) -- the call is then identical to hands_conv2d_nhwc_f32.
+ * workspace: hands_conv2d_streamk_workspace_bytes() bytes of device memory, ZEROED once by the caller, private to
+ * one stream at a time; epoch: any nonzero value different from the one passed with the previous call on the
+ * same workspace (a per-workspace counter). */
+long long hands_conv2d_streamk_workspace_bytes(void);
+int hands_conv2d_streamk_grid(const hands_conv_desc* d);
+int hands_conv2d_nhwc_streamk_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
+                                  const float* bias, const float* residual, float* out, void* workspace,
+                                  long long workspace_bytes, int epoch, hands_stream_t stream);
+
 /* Two 1x1 convolutions summed into one output: out = act(W0 * in + W1 * in2[stride2-sampled] + bias).
  * `d` describes the first one (stride 1, H = Ho, W = Wo, Cin = K0) with Kpad = K0 + Cin2; the packed
  * weight row is [W0 (K0) | W1 (Cin2)], both with their BatchNorm folded, bias = b0 + b1.  This is the

@@ -135,6 +135,47 @@ def test_conv_igemm_latency_mode_split_k(case):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
 
 
+SK_CASES = [
+    # B, Cin, H, Cout, k, stride, pad, residual        (tile counts chosen inside the stream-K window: 512 .. 16384)
+    (256, 256, 14, 256, 3, 1, 1, False),     # layer3 conv2 at bz=256: 392 x 2 = 784 tiles, 144 k-steps
+    (64, 512, 7, 512, 3, 1, 1, False),       # few tiles (below the window): plain launch, must still agree
+    (200, 1024, 14, 256, 1, 1, 0, False),    # pointwise, 64 k-steps
+    (150, 256, 14, 1024, 1, 1, 0, True),     # expand + residual + relu
+    (37, 128, 28, 128, 3, 2, 1, False),      # stride 2, ragged M
+    (300, 64, 14, 64, 3, 1, 1, False),       # narrow 256 x 64 tile instantiation
+]
+
+
+@pytest.mark.parametrize("case", SK_CASES)
+def test_stream_k_is_bit_identical_to_the_plain_launch(case):
+    """hands_conv2d_nhwc_streamk_f32: persistent workgroups with equal (tile, k-step) shares; a tile cut between
+    two workgroups continues the same fp32 FMA chain, so the output must equal hands_conv2d_nhwc_f32 BIT FOR BIT
+    (repeated launches on one workspace with a running epoch included)."""
+    B, Cin, H, Cout, k, stride, pad, use_res = case
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, H, Cin, generator=g).to(DEV)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    pc = pack_conv(w, torch.randn(Cout, generator=g), stride, pad, DEV)
+    Ho = (H + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Ho, Ho, Cout, generator=g).to(DEV) if use_res else None
+    plain, sk = ConvEngine(), ConvEngine()
+    plain.stream_k = False
+    ref = torch.full((B, Ho, Ho, pc.Cout), float("nan"), device=DEV)
+    plain.conv(L, pc, x, B, H, H, ref, True, _stream(), res=res)
+    d = _lib.ConvDesc(B, H, H, pc.Cin, Ho, Ho, pc.Cout, k, k, stride, pad, pc.Cin, pc.Cout, pc.Cout if use_res else 0, pc.Kpad, 1)
+    G = L.hands_conv2d_streamk_grid(C.byref(d))
+    for rep in range(3):
+        got = torch.full((B, Ho, Ho, pc.Cout), float("nan"), device=DEV)
+        sk.conv(L, pc, x, B, H, H, got, True, _stream(), res=res)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), (case, G, rep, (got - ref).abs().max().item())
+    if case is SK_CASES[0]:
+        assert G > 0 and G % 256 == 0, G
+    if case is SK_CASES[1]:
+        assert G == 0
+
+
 @pytest.mark.parametrize("case", [(2, 64, 64, 256, 56, 1), (3, 128, 256, 512, 28, 2), (1, 512, 1024, 2048, 14, 2), (2, 16, 32, 12, 9, 2)])
 def test_conv1x1_dual_vs_torch(case):
     """relu(conv1x1(x) + conv1x1_stride(x2) + bias): conv3 + downsample of a bottleneck as one GEMM."""
