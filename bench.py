@@ -223,7 +223,7 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
     model = model.to(ctx.dev).eval()
     model.latency_mode = bool(args.latency_mode)
     if os.environ.get("HANDS_STREAMK"):            # developer A/B switch
-        model.engine.stream_k = os.environ["HANDS_STREAMK"] == "1"
+        model.engine.stream_k = {"1": True, "0": False}.get(os.environ["HANDS_STREAMK"], "auto")
     if os.environ.get("HANDS_ASYNC_TAIL") and hasattr(model, "async_tail"):
         model.async_tail = os.environ["HANDS_ASYNC_TAIL"] == "1"
     model.overlap_trunks = not serial_headline

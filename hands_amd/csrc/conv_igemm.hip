@@ -74,7 +74,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
-// MODE 0: any convolution with Cin % 16 == 0; 1: the stem (Cin == 4, one filter tap per 16-byte chunk);
+// MODE 0: any convolution with Cin % 16 == 0 (k-steps ordered channel chunk, kh, kw); 1: the stem (Cin == 4, one filter tap per 16-byte chunk);
 // 2: two 1x1 convolutions summed into one output (k < K0 from `in`, the rest from `in2` sampled with
 //    its own stride) -- the last conv of a bottleneck fused with the block's downsample branch.
 constexpr int SK_SLOT_FLOATS = 4 * 64 * 64;   // one workgroup's accumulators: 4 waves x 64 registers x 64 lanes
@@ -125,7 +125,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
     x_hi0[i] = ho * a.stride - a.pad;
     x_wi0[i] = wo * a.stride - a.pad;
     x_base[i] = ((b * a.H + x_hi0[i]) * a.W + x_wi0[i]) * a.in_ps;
-    if constexpr (DUAL) x_base2[i] = ((b * a.H2 + ho * a.stride2) * a.W2 + wo * a.stride2) * a.in2_ps;
+    if constexpr (DUAL) {
+      x_base2[i] = ((b * a.H2 + ho * a.stride2) * a.W2 + wo * a.stride2) * a.in2_ps;
+    }
   }
   const float* wrow[W_ROWS];
 #pragma unroll
@@ -134,9 +136,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
   // staging registers (explicit scalars-of-float4: arrays captured by lambdas ended up in scratch)
   float4 xr[A_ROWS], wr[W_ROWS];
   // k-step state (wave-uniform for the regular path)
-  int kh = 0, kw = 0, c0 = 0;
+  int kh = 0, kw = 0, c0 = 0, woff = 0;
   const int ntaps = a.KH * a.KW;
-  const float* dual_src = a.in;
+  const int cw = (a.Cin & 31) == 0 ? 2 * BK : BK;   // channel chunk of the MODE 0 k order: one 128-B line when possible
 
 #define LOAD_TILES(KT)                                                                              \
   do {                                                                                              \
@@ -153,27 +155,35 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
                    : make_float4(0.f, 0.f, 0.f, 0.f);                                               \
       }                                                                                             \
     } else if constexpr (DUAL) {                                                                    \
-      if ((KT) * BK == a.K0) {               /* wave-uniform: switch to the second source once */   \
-        dual_src = a.in2 - a.K0;                                                                    \
-        _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) x_base[i] = x_base2[i];                  \
-      }                                                                                             \
-      /* rows past M were given the address of row 0 above: load unconditionally (their outputs */ \
-      /* are never stored), which keeps the k-loop free of branches                              */ \
+      /* wave-uniform source select (k < K0: `in`, else `in2` sampled with its own stride).  Rows   */ \
+      /* past M were given the address of row 0 above: load unconditionally (their outputs are     */ \
+      /* never stored), which keeps the k-loop free of branches                                    */ \
+      const bool second = (KT) * BK >= a.K0;                                                        \
+      const float* dsrc = second ? a.in2 - a.K0 : a.in;                                             \
       _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i)                                            \
-        xr[i] = *reinterpret_cast<const float4*>(dual_src + (x_base[i] + (KT) * BK + chunk * 4));   \
+        xr[i] = *reinterpret_cast<const float4*>(dsrc + ((second ? x_base2[i] : x_base[i]) + (KT) * BK + chunk * 4)); \
     } else {                                                                                        \
+      /* k order (chunk of cw channels, kh, kw, 16-channel step): the taps of one chunk re-read the  */ \
+      /* same 64-128 B of every pixel within a few k-steps, while the lines are still in the XCD's  */ \
+      /* L2; with taps outermost every tap pass streamed the whole tile again from HBM (8.6x)       */ \
+      const bool kvalid = c0 < a.Cin;          /* false only in caller-added zero padding of K */    \
       const int toff = (kh * a.W + kw) * a.in_ps + c0 + chunk * 4;                                  \
       _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) {                                          \
-        const bool ok = x_ok[i] && (unsigned)(x_hi0[i] + kh) < (unsigned)a.H &&                     \
+        const bool ok = kvalid && x_ok[i] && (unsigned)(x_hi0[i] + kh) < (unsigned)a.H &&           \
                         (unsigned)(x_wi0[i] + kw) < (unsigned)a.W;                                  \
         xr[i] = ok ? *reinterpret_cast<const float4*>(a.in + (x_base[i] + toff))                    \
                    : make_float4(0.f, 0.f, 0.f, 0.f);                                               \
       }                                                                                             \
+      woff = kvalid ? (kh * a.KW + kw) * a.Cin + c0 : (KT) * BK;                                    \
       c0 += BK;                                                                                     \
-      if (c0 >= a.Cin) { c0 = 0; if (++kw == a.KW) { kw = 0; ++kh; } }                              \
+      if ((c0 & (cw - 1)) == 0) {            /* chunk of cw channels done for this tap: next tap */  \
+        c0 -= cw;                                                                                   \
+        if (++kw == a.KW) { kw = 0; if (++kh == a.KH) { kh = 0; c0 += cw; } }                       \
+      }                                                                                             \
     }                                                                                               \
+    if constexpr (MODE != 0) woff = (KT) * BK;                                                      \
     _Pragma("unroll") for (int i = 0; i < W_ROWS; ++i)                                              \
-      wr[i] = *reinterpret_cast<const float4*>(wrow[i] + (KT) * BK);                                \
+      wr[i] = *reinterpret_cast<const float4*>(wrow[i] + woff);                                     \
   } while (0)
 
 #define STORE_TILES(BUF)                                                                            \
@@ -209,18 +219,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
 
   // running tap / source state at the first k-step of this segment
   if constexpr (MODE == 0) {
-    if (kt0 > 0) {
-      const int tap0 = (kt0 * BK) / a.Cin;
-      c0 = kt0 * BK - tap0 * a.Cin;
+    if (kt0 > 0) {                  // k-step kt = (chunk * ntaps + tap) * (cw / 16) + sub
+      const int spt = cw / BK;
+      const int ch0 = kt0 / (ntaps * spt);
+      const int r0 = kt0 - ch0 * ntaps * spt;
+      const int tap0 = r0 / spt;
+      c0 = ch0 * cw + (r0 - tap0 * spt) * BK;
       kh = tap0 / a.KW;
       kw = tap0 - kh * a.KW;
-    }
-  }
-  if constexpr (DUAL) {
-    if (kt0 * BK > a.K0) {        // segment starts inside the second source
-      dual_src = a.in2 - a.K0;
-#pragma unroll
-      for (int i = 0; i < A_ROWS; ++i) x_base[i] = x_base2[i];
     }
   }
   LOAD_TILES(kt0);

@@ -25,7 +25,11 @@ class ConvEngine:
         self.overlap = True           # run independent jobs (trunks, heads, crop chunks) on side HIP streams
         self.fuse_stem_pool = True    # stem conv + BN + act + max-pool as one kernel (csrc/stem_pool.hip)
         self.fuse_downsample = True   # first block of a stage: conv3 + downsample + add + ReLU as one two-source GEMM
-        self.stream_k = True          # persistent stream-K launches where the tile count quantises badly (bit-identical)
+        self.stream_k = "auto"        # persistent stream-K launches where the tile count quantises badly (bit-identical
+                                      # to the plain launch).  "auto": only when the launch has the chip to itself
+                                      # (overlap off: +5 % measured); with several streams in flight the other
+                                      # streams' workgroups already fill the tail and persistent workgroups would
+                                      # only hold their slots (-1.7 % measured).  True / False force it.
         self.fuse_mano = True         # MANOHead.forward of both hands as one launch (hands_mano_heads_f32)
         self.hook = None              # callable(phase, pc, npix, stream_handle, has_res, kernel): bench.py brackets
                                       # every MFMA launch (conv_igemm and the fused stem) with events
@@ -79,7 +83,8 @@ class ConvEngine:
             check(L.hands_conv2d_nhwc_splitk_n_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
                                                    ptr(res, res_off) if res is not None else None, ptr(out, out_off),
                                                    S, ptr(ws), ws.numel(), stream), "hands_conv2d_nhwc_splitk_n_f32")
-        elif self.stream_k and L.hands_conv2d_streamk_grid(C.byref(d)) > 0:
+        elif ((not self.overlap) if self.stream_k == "auto" else self.stream_k) and \
+                L.hands_conv2d_streamk_grid(C.byref(d)) > 0:
             key = (x.device, stream)
             sk = self._sk_ws.get(key)
             if sk is None:

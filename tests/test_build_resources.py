@@ -1,0 +1,28 @@
+"""Build-time guard: no kernel of the GEMM / convolution file may spill registers to scratch memory.
+(A runtime-indexed staging array once went to scratch silently: the pointwise layers wrote 2-4x their output
+bytes to HBM and the whole forward lost 6 %.)  Compiles conv_igemm.hip with the resource-usage remarks on."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("src", ["conv_igemm.hip", "mano_lbs.hip", "stem_pool.hip"])
+def test_hot_kernels_do_not_spill(tmp_path, src):
+    p = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{ROOT}/hands_amd/csrc",
+                        "-fno-fast-math", "-ffp-contract=off", "-Rpass-analysis=kernel-resource-usage", "-c",
+                        os.path.join(ROOT, "hands_amd", "csrc", src), "-o", str(tmp_path / "o.o")],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", p.stderr)
+    scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", p.stderr)]
+    spills = [int(v) for v in re.findall(r"VGPRs Spill: (\d+)", p.stderr)]
+    assert names and len(names) == len(scratch) == len(spills)
+    bad = [(n, s, v) for n, s, v in zip(names, scratch, spills) if s or v]
+    assert not bad, bad

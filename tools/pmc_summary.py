@@ -13,7 +13,7 @@ fetch_csv, write_csv, workload, out = sys.argv[1:5]
 def total(fn, counter):
     tot, disp = 0.0, set()
     for r in csv.DictReader(open(fn)):
-        if "conv_igemm_f32_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if "conv_igemm" in r["Kernel_Name"] and r["Counter_Name"] == counter:
             tot += float(r["Counter_Value"])
             disp.add(r["Dispatch_Id"])
     return tot, len(disp)
@@ -23,9 +23,9 @@ def by_grid(fn, counter):
     """per (template instantiation, grid size): [dispatches, KB] -- which launch shapes carry the traffic"""
     g = {}
     for r in csv.DictReader(open(fn)):
-        if "conv_igemm_f32_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if "conv_igemm" in r["Kernel_Name"] and r["Counter_Name"] == counter:
             inst = r["Kernel_Name"].split("<")[1].split(">")[0].replace(" ", "") if "<" in r["Kernel_Name"] else "?"
-            key = f"<{inst}> grid={r.get('Grid_Size', '?')}"
+            key = ("sk" if "_sk_" in r["Kernel_Name"] else "") + f"<{inst}> grid={r.get('Grid_Size', '?')}"
             d = g.setdefault(key, [set(), 0.0])
             d[0].add(r["Dispatch_Id"])
             d[1] += float(r["Counter_Value"])
@@ -35,7 +35,7 @@ def by_grid(fn, counter):
 f, nf = total(fetch_csv, "FETCH_SIZE")
 w, nw = total(write_csv, "WRITE_SIZE")
 assert nf == nw and nf > 0, (nf, nw)
-res = {"workload": workload, "kernel": "conv_igemm_f32_kernel", "dispatches": nf,
+res = {"workload": workload, "kernel": "conv_igemm_f32_kernel + conv_igemm_sk_f32_kernel", "dispatches": nf,
        "fetch_size_kb_sum": f, "write_size_kb_sum": w, "fetch_correction": 2.0,
        "hbm_gb_per_launch": (2.0 * f + w) * 1024 / nf / 1e9,
        "read_gb_per_launch": 2.0 * f * 1024 / nf / 1e9, "write_gb_per_launch": w * 1024 / nf / 1e9,
