@@ -211,7 +211,7 @@ def workload_text(workload, bz, world):
 # ------------------------------------------------------------------------------------------------------
 # model workloads (hands_light / hamer_light / handoccnet_light)
 # ------------------------------------------------------------------------------------------------------
-def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False, parity_bz=0, layer_report=""):
+def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False, parity_bz=0, layer_report="", math="fp32"):
     """Returns (result dict, model, cpu state_dict) -- result holds value / ms_per_step / roofline / serial /
     overlapped (+ parity vs the oracle on ``parity_bz`` samples when > 0, rank 0 only)."""
     torch = ctx.torch
@@ -222,8 +222,11 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if (ctx.rank == 0 and parity_bz) else None
     model = model.to(ctx.dev).eval()
     model.latency_mode = bool(args.latency_mode)
+    model.engine.math = math
     if os.environ.get("HANDS_STREAMK"):            # developer A/B switch
         model.engine.stream_k = {"1": True, "0": False}.get(os.environ["HANDS_STREAMK"], "auto")
+    if os.environ.get("HANDS_MATH"):               # developer switch; the default line is always exact fp32
+        model.engine.math = os.environ["HANDS_MATH"]
     if os.environ.get("HANDS_ASYNC_TAIL") and hasattr(model, "async_tail"):
         model.async_tail = os.environ["HANDS_ASYNC_TAIL"] == "1"
     model.overlap_trunks = not serial_headline
@@ -579,14 +582,25 @@ def main():
         torch.cuda.empty_cache()
         also = {}
         t_also = time.perf_counter()
-        for name, abz, asteps, awarm, pbz in (("hamer_light", 64, 4, 1, 1), ("handoccnet_light", 32, 10, 3, 2)):
+        for name, abz, asteps, awarm, pbz in (("hands_light_bf16x3", 256, 10, 3, 8), ("hamer_light", 64, 4, 1, 1),
+                                              ("handoccnet_light", 32, 10, 3, 2)):
             try:
-                r, m, sd = measure_model(ctx, name, abz, asteps, awarm, args, parity_bz=pbz)
+                math = "fp32"
+                if name.endswith("_bf16x3"):
+                    # separately reported arithmetic mode (HANDS_MATH_BF16X3): three exact bf16 planes per operand,
+                    # six bf16 MFMAs per k-16 step, fp32 accumulation.  NEVER the headline `value` above.
+                    name, math = name[: -len("_bf16x3")], "bf16x3"
+                r, m, sd = measure_model(ctx, name, abz, asteps, awarm, args, parity_bz=pbz, math=math)
+                if math != "fp32":
+                    r["math"] = ("bf16x3: fp32 operands split on the fly into 3 exact bf16 planes, products b_i*b_j with i+j<=2 on "
+                                 "v_mfma_f32_32x32x16_bf16, fp32 accumulation; stem, split-K heads, attention and MANO stay fp32 MFMA")
+                    r["roofline"]["note"] = ("achieved = ALGORITHMIC fp32 FLOPs / time, priced against the fp32-MFMA peak for "
+                                             "comparison with the exact path; the kernel executes 6 bf16 MFMAs per k-16 step")
                 r["parity"] = parity_vs_oracle(ctx, name, m, sd, pbz)
                 r["config"] = {"workload": workload_text(name, abz, 1), "per_gpu_batch": abz, "steps": asteps, "warmup": awarm}
                 if name == "handoccnet_light":
                     r["config"]["note"] = "BASELINE configs[3] is bz=256 over 8 GPUs: this is one GPU's 32-sample shard"
-                also[name] = r
+                also[name if math == "fp32" else name + "_" + math] = r
                 del m, sd
                 torch.cuda.empty_cache()
             except Exception as e:       # the headline line must survive a failure of an extra measurement

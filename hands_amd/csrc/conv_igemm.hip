@@ -46,6 +46,28 @@ __device__ __forceinline__ float f4elem(const float4& v, int t) {
 
 constexpr int BK = 16;         // floats per k-step
 constexpr int LDS_ROW = 20;    // padded LDS row (floats): 80 B = 5 x 16 B slots
+constexpr int LDS_ROW_B3 = 28; // bf16x3 mode: three bf16 planes of 16 k (3 x 32 B) + 16 B pad = 112 B = 7 slots (odd)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// fp32 = b0 + b1 + b2 EXACTLY, each a bf16 (8 significant bits): truncation takes the top 8 bits, the exact
+// remainder has at most 16, then 8 significant bits.  (inf / NaN inputs give NaN.)
+__device__ __forceinline__ void split3(float x, uint32_t& u0, uint32_t& u1, uint32_t& u2) {
+  u0 = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(u0);
+  u1 = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(u1);
+  u2 = __float_as_uint(r2);          // <= 8 significant bits: its low half is zero already
+}
+
+// four consecutive k of one row -> three planes of 4 bf16 (8 B each) at dst + plane * 8 floats
+__device__ __forceinline__ void store_split4(float* dst, float4 v) {
+  uint32_t a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
+  split3(v.x, a0, a1, a2); split3(v.y, b0, b1, b2); split3(v.z, c0, c1, c2); split3(v.w, d0, d1, d2);
+  *reinterpret_cast<uint2*>(dst) = make_uint2((a0 >> 16) | b0, (c0 >> 16) | d0);
+  *reinterpret_cast<uint2*>(dst + 8) = make_uint2((a1 >> 16) | b1, (c1 >> 16) | d1);
+  *reinterpret_cast<uint2*>(dst + 16) = make_uint2((a2 >> 16) | (b2 & 0xffff0000u), (c2 >> 16) | (d2 & 0xffff0000u));
+}
 
 struct ConvArgs {
   const float* __restrict__ in;
@@ -82,9 +104,14 @@ constexpr int SK_SLOT_FLOATS = 4 * 64 * 64;   // one workgroup's accumulators: 4
 // One output tile (BM pixels x BN channels), k-steps [kt0, kt1).  acc_in != nullptr: the accumulators continue a
 // chain another workgroup started (stream-K hand-off, register layout); acc_out != nullptr: dump the raw
 // accumulators there instead of running the epilogue.  `split` is the slice index of the split-K form.
-template <int WAVES_M, int WAVES_N, int MODE>
+// PREC 0: exact fp32 (v_mfma_f32_32x32x2_f32).  PREC 1 ("bf16x3", a separately reported mode, never the default):
+// both operands are split on the way into LDS into three bf16 planes whose sum is the fp32 value exactly, and a
+// k-16 step is six v_mfma_f32_32x32x16_bf16 (the products b_i * b_j with i + j <= 2, fp32 accumulation): the
+// dropped terms are <= 2^-24 of a product -- fp32-grade results at 3/8 of the matrix-pipe time.
+template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int tile, int split, int kt0, int kt1,
                                           const float* acc_in, float* acc_out) {
+  constexpr int ROW = PREC ? LDS_ROW_B3 : LDS_ROW;
   constexpr bool STEM = MODE == 1;
   constexpr bool DUAL = MODE == 2;
   constexpr int BM = 64 * WAVES_M;
@@ -93,8 +120,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
   constexpr int W_ROWS = BN / 64;   // weight rows staged per thread
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
 
-  float* sX = lds;                          // [2][BM][LDS_ROW]
-  float* sW = lds + 2 * BM * LDS_ROW;       // [2][BN][LDS_ROW]
+  float* sX = lds;                          // [2][BM][ROW]
+  float* sW = lds + 2 * BM * ROW;       // [2][BN][ROW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -188,12 +215,19 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
 
 #define STORE_TILES(BUF)                                                                            \
   do {                                                                                              \
-    float* dx = sX + (BUF) * BM * LDS_ROW + srow * LDS_ROW + chunk * 4;                             \
-    float* dw = sW + (BUF) * BN * LDS_ROW + srow * LDS_ROW + chunk * 4;                             \
-    _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i)                                              \
-      *reinterpret_cast<float4*>(dx + 64 * i * LDS_ROW) = xr[i];                                    \
-    _Pragma("unroll") for (int i = 0; i < W_ROWS; ++i)                                              \
-      *reinterpret_cast<float4*>(dw + 64 * i * LDS_ROW) = wr[i];                                    \
+    if constexpr (PREC == 0) {                                                                      \
+      float* dx = sX + (BUF) * BM * ROW + srow * ROW + chunk * 4;                                   \
+      float* dw = sW + (BUF) * BN * ROW + srow * ROW + chunk * 4;                                   \
+      _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i)                                            \
+        *reinterpret_cast<float4*>(dx + 64 * i * ROW) = xr[i];                                      \
+      _Pragma("unroll") for (int i = 0; i < W_ROWS; ++i)                                            \
+        *reinterpret_cast<float4*>(dw + 64 * i * ROW) = wr[i];                                      \
+    } else {                                                                                        \
+      float* dx = sX + (BUF) * BM * ROW + srow * ROW + chunk * 2;                                   \
+      float* dw = sW + (BUF) * BN * ROW + srow * ROW + chunk * 2;                                   \
+      _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) store_split4(dx + 64 * i * ROW, xr[i]);    \
+      _Pragma("unroll") for (int i = 0; i < W_ROWS; ++i) store_split4(dw + 64 * i * ROW, wr[i]);    \
+    }                                                                                               \
   } while (0)
 
   f32x16 acc[2][2];
@@ -234,25 +268,46 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
   __syncthreads();
 
   // fragment read offsets: row = lane&31, k half = lane>>5
-  const int frag = (lane & 31) * LDS_ROW + (lane >> 5) * 4;
-  const float* fw = sW + (wn * 64) * LDS_ROW + frag;
-  const float* fx = sX + (wm * 64) * LDS_ROW + frag;
+  const int frag = (lane & 31) * ROW + (lane >> 5) * 4;
+  const float* fw = sW + (wn * 64) * ROW + frag;
+  const float* fx = sX + (wm * 64) * ROW + frag;
 
 #define COMPUTE_STEP(BUF)                                                                           \
   do {                                                                                              \
-    float4 wf[2][2], xf[2][2]; /* [32-row block][kk] */                                             \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                              \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                               \
-        wf[i][kk] = *reinterpret_cast<const float4*>(fw + (BUF) * BN * LDS_ROW + i * 32 * LDS_ROW + kk * 8); \
-        xf[i][kk] = *reinterpret_cast<const float4*>(fx + (BUF) * BM * LDS_ROW + i * 32 * LDS_ROW + kk * 8); \
+    if constexpr (PREC == 0) {                                                                      \
+      float4 wf[2][2], xf[2][2]; /* [32-row block][kk] */                                           \
+      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                            \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                             \
+          wf[i][kk] = *reinterpret_cast<const float4*>(fw + (BUF) * BN * ROW + i * 32 * ROW + kk * 8); \
+          xf[i][kk] = *reinterpret_cast<const float4*>(fx + (BUF) * BM * ROW + i * 32 * ROW + kk * 8); \
+        }                                                                                           \
       }                                                                                             \
-    }                                                                                               \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                              \
-      _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                               \
+      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                            \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                             \
+          _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                           \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                         \
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4elem(wf[i][kk], t), f4elem(xf[j][kk], t), \
+                                                               acc[i][j], 0, 0, 0);                  \
+            }                                                                                       \
+          }                                                                                         \
+        }                                                                                           \
+      }                                                                                             \
+    } else {                                                                                        \
+      /* lane (row = lane & 31, half = lane >> 5) holds k = 8 * half .. + 7 of its row, per plane */  \
+      bf16x8 wf[2][3], xf[2][3]; /* [32-row block][plane] */                                        \
+      _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                             \
+          wf[i][p] = *reinterpret_cast<const bf16x8*>(fw + (BUF) * BN * ROW + i * 32 * ROW + p * 8); \
+          xf[i][p] = *reinterpret_cast<const bf16x8*>(fx + (BUF) * BM * ROW + i * 32 * ROW + p * 8); \
+        }                                                                                           \
+      }                                                                                             \
+      /* products b_pa(w) * b_pb(x) with pa + pb <= 2, smallest terms first */                       \
+      _Pragma("unroll") for (int q = 0; q < 6; ++q) {                                               \
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0};                                                   \
+        constexpr int PB[6] = {0, 1, 2, 0, 1, 0};                                                   \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                             \
           _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                           \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4elem(wf[i][kk], t), f4elem(xf[j][kk], t), \
-                                                             acc[i][j], 0, 0, 0);                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][PA[q]], xf[j][PB[q]], acc[i][j], 0, 0, 0); \
           }                                                                                         \
         }                                                                                           \
       }                                                                                             \
@@ -334,9 +389,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
 #undef STORE_TILES
 }
 
-template <int WAVES_M, int WAVES_N, int MODE>
+template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0>
 __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * (64 * WAVES_M + 64 * WAVES_N) * LDS_ROW];
+  __shared__ __attribute__((aligned(16))) float lds[2 * (64 * WAVES_M + 64 * WAVES_N) * (PREC ? LDS_ROW_B3 : LDS_ROW)];
   const int ntiles = a.nblk_m * a.nblk_n;
   const int split = a.ksplit > 1 ? blockIdx.x / ntiles : 0;
   const int tile = xcd_remap(a.ksplit > 1 ? blockIdx.x - split * ntiles : blockIdx.x, ntiles);
@@ -344,7 +399,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   const int nk_all = a.Kpad / BK;
   const int kt0 = a.ksplit > 1 ? (int)((long long)split * nk_all / a.ksplit) : 0;
   const int kt1 = a.ksplit > 1 ? (int)((long long)(split + 1) * nk_all / a.ksplit) : nk_all;
-  conv_tile<WAVES_M, WAVES_N, MODE>(a, lds, tile, split, kt0, kt1, nullptr, nullptr);
+  conv_tile<WAVES_M, WAVES_N, MODE, PREC>(a, lds, tile, split, kt0, kt1, nullptr, nullptr);
 }
 
 // ---- stream-K: persistent workgroups with equal shares of (tile, k-step) units -------------------------------
@@ -419,14 +474,14 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sk_f32_kernel(ConvArgs a, S
   }
 }
 
-template <int WAVES_M, int WAVES_N, int MODE>
+template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0>
 int launch(ConvArgs& a, hipStream_t stream) {
   constexpr int BM = 64 * WAVES_M, BN = 64 * WAVES_N;
   a.nblk_m = (a.M + BM - 1) / BM;
   a.nblk_n = (a.N + BN - 1) / BN;
   const long long nwg = (long long)a.nblk_m * a.nblk_n * (a.ksplit > 1 ? a.ksplit : 1);
   if (nwg <= 0 || nwg > 0x7fffffffLL) return HANDS_EINVAL;
-  hipLaunchKernelGGL((conv_igemm_f32_kernel<WAVES_M, WAVES_N, MODE>), dim3((unsigned)nwg), dim3(256), 0,
+  hipLaunchKernelGGL((conv_igemm_f32_kernel<WAVES_M, WAVES_N, MODE, PREC>), dim3((unsigned)nwg), dim3(256), 0,
                      stream, a);
   return (int)hipGetLastError();
 }
@@ -578,11 +633,15 @@ extern "C" int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, 
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
-  a.relu = d->act;
+  a.relu = d->act & HANDS_ACT_MASK;
   a.ksplit = 1; a.partial = nullptr; a.part_ps = 0;
   a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
   hipStream_t s = (hipStream_t)stream;
   if (stem) return (d->Cout <= 64) ? launch<4, 1, 1>(a, s) : launch<2, 2, 1>(a, s);
+  if (d->act & HANDS_MATH_BF16X3) {
+    if (pointwise_route_ok(d)) return (d->Cout <= 64) ? launch<4, 1, 2, 1>(a, s) : launch<2, 2, 2, 1>(a, s);
+    return (d->Cout <= 64) ? launch<4, 1, 0, 1>(a, s) : launch<2, 2, 0, 1>(a, s);
+  }
   // pointwise layers (1x1, no padding; any stride) take the two-source instantiation with the switch
   // point out of reach: no tap state and no bounds checks in the k-loop
   if (pointwise_route_ok(d)) return (d->Cout <= 64) ? launch<4, 1, 2>(a, s) : launch<2, 2, 2>(a, s);
@@ -613,7 +672,8 @@ extern "C" int hands_conv2d_nhwc_streamk_f32(const hands_conv_desc* d, const flo
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
-  a.relu = d->act;
+  if (d->act & HANDS_MATH_BF16X3) return hands_conv2d_nhwc_f32(d, in, w_packed, bias, residual, out, stream);
+  a.relu = d->act & HANDS_ACT_MASK;
   a.ksplit = 1; a.partial = nullptr; a.part_ps = 0;
   a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
   hipStream_t s = (hipStream_t)stream;
@@ -642,10 +702,11 @@ extern "C" int hands_conv1x1_dual_nhwc_f32(const hands_conv_desc* d, const float
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
   a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0;
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = 0;
-  a.relu = d->act;
+  a.relu = d->act & HANDS_ACT_MASK;
   a.ksplit = 1; a.partial = nullptr; a.part_ps = 0;
   a.in2 = in2; a.K0 = d->Cin; a.H2 = H2; a.W2 = W2; a.stride2 = stride2; a.in2_ps = in2_pix_stride;
   hipStream_t s = (hipStream_t)stream;
+  if (d->act & HANDS_MATH_BF16X3) return (d->Cout <= 64) ? launch<4, 1, 2, 1>(a, s) : launch<2, 2, 2, 1>(a, s);
   return (d->Cout <= 64) ? launch<4, 1, 2>(a, s) : launch<2, 2, 2>(a, s);
 }
 
@@ -677,7 +738,7 @@ extern "C" int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const fl
   if (rc) return rc;
   const long long total = M * (d->Cout / 4);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(hands_grid_1d(total, 256)), dim3(256), 0, s, workspace, S, (int)M,
-                     d->Cout / 4, part_ps, bias, residual, d->res_pix_stride, out, d->out_pix_stride, d->act);
+                     d->Cout / 4, part_ps, bias, residual, d->res_pix_stride, out, d->out_pix_stride, d->act & HANDS_ACT_MASK);
   return (int)hipGetLastError();
 }
 

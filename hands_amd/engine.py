@@ -15,6 +15,8 @@ import torch
 
 from ._lib import ConvDesc, check, ptr
 
+MATH_BF16X3 = 0x100   # HANDS_MATH_BF16X3 (include/hands_hip.h)
+
 
 class ConvEngine:
     def __init__(self):
@@ -30,6 +32,9 @@ class ConvEngine:
                                       # (overlap off: +5 % measured); with several streams in flight the other
                                       # streams' workgroups already fill the tail and persistent workgroups would
                                       # only hold their slots (-1.7 % measured).  True / False force it.
+        self.math = "fp32"            # "fp32" = exact fp32 MFMA (the parity path, the default).  "bf16x3" = separately
+                                      # reported mode: operands split into three exact bf16 planes, six bf16 MFMAs per
+                                      # k-16 step with fp32 accumulation (HANDS_MATH_BF16X3); never the headline
         self.fuse_mano = True         # MANOHead.forward of both hands as one launch (hands_mano_heads_f32)
         self.hook = None              # callable(phase, pc, npix, stream_handle, has_res, kernel): bench.py brackets
                                       # every MFMA launch (conv_igemm and the fused stem) with events
@@ -38,7 +43,7 @@ class ConvEngine:
 
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
-        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "fuse_mano", "stream_k"):
+        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "fuse_mano", "stream_k", "math"):
             setattr(e, k, getattr(self, k))
         return e
 
@@ -65,7 +70,7 @@ class ConvEngine:
         d = ConvDesc(B, H, W, pc.Cin, Ho, Wo, pc.Cout, pc.KH, pc.KW, pc.stride, pc.pad,
                      in_ps or pc.Cin, out_ps or pc.Cout,
                      (pc.Cout if res_ps is None else res_ps) if res is not None else 0,
-                     pc.Kpad, int(relu))   # relu: bool or a HANDS_ACT_* code
+                     pc.Kpad, int(relu) | (MATH_BF16X3 if self.math == "bf16x3" else 0))   # relu: bool or a HANDS_ACT_* code
         hook = self.hook
         if hook is not None:
             hook("begin", pc, B * Ho * Wo, stream, res is not None, "conv_igemm_f32_kernel")
@@ -83,7 +88,7 @@ class ConvEngine:
             check(L.hands_conv2d_nhwc_splitk_n_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
                                                    ptr(res, res_off) if res is not None else None, ptr(out, out_off),
                                                    S, ptr(ws), ws.numel(), stream), "hands_conv2d_nhwc_splitk_n_f32")
-        elif ((not self.overlap) if self.stream_k == "auto" else self.stream_k) and \
+        elif self.math == "fp32" and ((not self.overlap) if self.stream_k == "auto" else self.stream_k) and \
                 L.hands_conv2d_streamk_grid(C.byref(d)) > 0:
             key = (x.device, stream)
             sk = self._sk_ws.get(key)
@@ -107,7 +112,8 @@ class ConvEngine:
     def conv_dual(self, L, pc, split, x, x2, B, Ho, Wo, H2, W2, out, stream, act=1, out_off=0):
         """act(conv3(x) + downsample(x2)) (resnet.py:146-154) with the identity never materialised."""
         K0, K1, stride2 = split
-        d = ConvDesc(B, Ho, Wo, K0, Ho, Wo, pc.Cout, 1, 1, 1, 0, K0, pc.Cout, 0, pc.Kpad, int(act))
+        d = ConvDesc(B, Ho, Wo, K0, Ho, Wo, pc.Cout, 1, 1, 1, 0, K0, pc.Cout, 0, pc.Kpad,
+                     int(act) | (MATH_BF16X3 if self.math == "bf16x3" else 0))
         hook = self.hook
         if hook is not None:
             hook("begin", pc, B * Ho * Wo, stream, False, "conv_igemm_f32_kernel")

@@ -62,6 +62,14 @@ typedef struct hands_conv_desc {
 #define HANDS_ACT_RELU 1
 #define HANDS_ACT_GELU 2        /* nn.GELU(): x*0.5*(1+erf(x/sqrt(2)))  (vit.py:76, pose_transformer.py:44) */
 #define HANDS_ACT_LEAKY_RELU 3  /* negative slope 0.01 (handoccnet_light/backbone.py) */
+#define HANDS_ACT_MASK 0xff
+/* Optional arithmetic flag OR'ed into desc.act (default 0 = exact fp32 MFMA, the parity path): both operands are
+ * split on the fly into three bf16 planes whose sum is the fp32 value exactly, and the products b_i * b_j with
+ * i + j <= 2 run on the bf16 matrix pipe with fp32 accumulation (dropped terms <= 2^-24 of a product).  A separately
+ * reported mode: results are fp32-grade but NOT bit-identical to the fp32 chain.  Honoured by
+ * hands_conv2d_nhwc_f32 and hands_conv1x1_dual_nhwc_f32 (not the RGB0 stem); the split-K / stream-K entries
+ * ignore it (fp32). */
+#define HANDS_MATH_BF16X3 0x100
 
 int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
                           const float* bias, const float* residual, float* out,

@@ -605,6 +605,45 @@ def test_replica_on_a_second_stream(gpu_model):
             assert torch.equal(o[k], ref[k]), k
 
 
+@pytest.mark.parametrize("case", CONV_CASES + [(2, 64, 28, 28, 256, 1, 1, 0, True, True)])
+def test_conv_bf16x3_mode_is_fp32_grade(case):
+    """HANDS_MATH_BF16X3 (separately reported mode): operands split exactly into three bf16 planes, six bf16 MFMAs per
+    k-16 step, fp32 accumulation.  Same error bar against an fp64 convolution as the exact fp32 path."""
+    B, Cin, H, W, Cout, k, stride, pad, relu, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.logspace(-3, 3, Cin).view(1, Cin, 1, 1)   # 6 decades of scale
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5 / torch.logspace(-3, 3, Cin).view(1, Cin, 1, 1)
+    bias = torch.randn(Cout, generator=g)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Cout, Ho, Wo, generator=g) if use_res else None
+    ref = F.conv2d(x.double(), w.double(), bias.double(), stride=stride, padding=pad)
+    if res is not None:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    eng = ConvEngine()
+    eng.math = "bf16x3"
+    got = _run_conv(x, w, bias, stride, pad, relu, res, engine=eng)
+    exact = _run_conv(x, w, bias, stride, pad, relu, res)
+    scale = max(1.0, ref.abs().max().item())
+    err, err32 = (got.double() - ref).abs().max().item(), (exact.double() - ref).abs().max().item()
+    assert err < 2e-5 * scale and err < 4 * err32 + 1e-7 * scale, (err, err32)
+
+
+def test_forward_bf16x3_mode_vs_golden(golden_dir, recipe_model):
+    """The whole forward in the bf16x3 mode against the reference-generated fixture: the same 1e-6 m / 1e-3 mm bar."""
+    import copy
+    model = copy.deepcopy(recipe_model).to(DEV)
+    model.engine.math = "bf16x3"
+    d = np.load(os.path.join(golden_dir, "hands_light_bz2_seed0.npz"))
+    inputs, meta_info = synthetic_inputs(2, 0, device=DEV)
+    out = model(inputs, meta_info)
+    for hn in "rl":
+        verr = np.abs(out[f"mano.vertices.{hn}"].cpu().numpy() - d[f"out/mano.vertices.{hn}"]).max()
+        assert verr < 1e-6, verr
+        assert O.mpjpe_ra_mm(out[f"mano.joints3d.{hn}"].cpu(), torch.from_numpy(d[f"out/mano.joints3d.{hn}"])) < 1e-3
+
+
 def test_async_tail_keeps_stream_semantics(gpu_model):
     """The forward's tail runs on its own stream and the result joins at first use: results are bit-identical
     to the synchronous path; inputs may be overwritten right after forward() returns; several un-consumed
