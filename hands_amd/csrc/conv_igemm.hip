@@ -46,7 +46,8 @@ __device__ __forceinline__ float f4elem(const float4& v, int t) {
 
 constexpr int BK = 16;         // floats per k-step
 constexpr int LDS_ROW = 20;    // padded LDS row (floats): 80 B = 5 x 16 B slots
-constexpr int LDS_ROW_B3 = 28; // bf16x3 mode: three bf16 planes of 16 k (3 x 32 B) + 16 B pad = 112 B = 7 slots (odd)
+constexpr int LDS_ROW_B3 = 24; // bf16x3 mode: three bf16 planes of 16 k (3 x 32 B), no pad: 2-way read conflicts, but 49 KB
+                               // per block = 3 blocks per CU (measured +8 % over the padded 112-B rows at 2 blocks per CU)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
