@@ -583,7 +583,7 @@ def main():
         also = {}
         t_also = time.perf_counter()
         for name, abz, asteps, awarm, pbz in (("hands_light_bf16x3", 256, 10, 3, 8), ("hamer_light", 64, 4, 1, 1),
-                                              ("handoccnet_light", 32, 10, 3, 2)):
+                                              ("hamer_light_bf16x3", 64, 4, 1, 1), ("handoccnet_light", 32, 10, 3, 2)):
             try:
                 math = "fp32"
                 if name.endswith("_bf16x3"):
