@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/build_variant.sh <name> [git-ref|-] [replacement conv_igemm.hip]
+# usage: tools/build_variant.sh <name> [git-ref|-] [replacement file] [file name it replaces, default conv_igemm.hip]
 #   -> build_ab/<name>.so from the working tree (ref "-" or empty) or from csrc/ at <git-ref>
 # A/B on ONE box (boxes differ by ~6 %): HANDS_HIP_LIB=build_ab/<name>.so python bench.py ...
 set -e
@@ -14,7 +14,7 @@ if [ -n "$REF" ]; then
 else
   cp $R/hands_amd/csrc/*.hip $R/hands_amd/csrc/*.h $R/hands_amd/csrc/*.cpp $D/; cp $R/include/hands_hip.h $D/
 fi
-if [ -n "$REPL" ]; then cp $REPL $D/conv_igemm.hip; fi
+if [ -n "$REPL" ]; then cp $REPL $D/${4:-conv_igemm.hip}; fi
 cd $D
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I. -fno-fast-math -ffp-contract=off -Wno-unused-function"
 OBJS=""
