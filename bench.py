@@ -159,7 +159,10 @@ class Ctx:
             else:
                 dist.init_process_group(self.backend)
         self.rccl_ranks = dist.get_world_size() if self.world > 1 else 1
-        self.host_collective = self.world > 1 and self.backend != "nccl"
+        # gloo dry runs gather host copies unless HANDS_BENCH_GLOO_DEVICE=1 (gloo stages device tensors itself:
+        # that exercises the same stream-ordered gather path RCCL takes)
+        self.host_collective = (self.world > 1 and self.backend != "nccl" and
+                                os.environ.get("HANDS_BENCH_GLOO_DEVICE") != "1")
 
     def fence(self):
         self.torch.cuda.synchronize(self.dev)
@@ -170,7 +173,7 @@ class Ctx:
     def max_over_ranks(self, seconds):
         if self.world == 1:
             return seconds
-        t = self.torch.tensor([seconds], dtype=self.torch.float64, device="cpu" if self.host_collective else self.dev)
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device="cpu" if self.backend != "nccl" else self.dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 

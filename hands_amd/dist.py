@@ -17,7 +17,9 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
-from .xdict import xdict
+from .xdict import stream_xdict, xdict
+
+_gather_streams = {}   # device -> side stream the asynchronous gather runs on
 
 
 def shard_range(bz: int, rank: int, world: int):
@@ -85,7 +87,20 @@ def gather_predictions(out: dict, group=None, global_bz: int | None = None) -> x
     the ranks hold the ``shard_range(global_bz, rank, world)`` shards (possibly uneven or empty): buffers
     are padded to the largest shard before the collective and trimmed after it."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return xdict(out)
+        return out if isinstance(out, xdict) else xdict(out)
+    if isinstance(out, stream_xdict) and out.is_pending:
+        # the forward's tail is still running on its own stream: pack + all-gather on a side stream ordered after
+        # it and hand back another stream-ordered dict, so the caller's stream (the next forward's trunks) never
+        # waits for this forward's tail or for the collective
+        dev = out.__dict__["_device"]
+        st = _gather_streams.get(dev)
+        if st is None:
+            st = _gather_streams[dev] = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            res = gather_predictions(xdict(out), group, global_bz)     # joins on `st`, collective ordered after it
+            ready = torch.cuda.Event()
+            ready.record(st)
+        return stream_xdict(res, ready, dev)
     world = dist.get_world_size(group)
     rows = None if global_bz is None else max_shard(global_bz, world)
     flat, layout = pack_predictions(out, rows)

@@ -14,6 +14,7 @@ import torch.distributed as dist
 
 def main():
     out_path, bz, seed = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    on_host = len(sys.argv) <= 4 or sys.argv[4] != "device"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import hands_amd
@@ -22,9 +23,11 @@ def main():
     model = hands_amd.apply_recipe(hands_amd.HandsLight()).to(dev).eval()
     inputs, meta = hands_amd.synthetic_inputs(bz, seed, device=dev)        # every rank holds the GLOBAL batch
     meta["is_flipped"] = (torch.arange(bz, device=dev) % 3 == 1).long()
-    got = data_parallel_forward(model, inputs, meta, gather_on_host=True)
+    # "device": the gather takes the stream-ordered path RCCL takes (pending stream_xdict -> pack and collective on
+    # a side stream, gloo staging the device tensors itself); default: host copies
+    got = data_parallel_forward(model, inputs, meta, gather_on_host=on_host)
     if rank == 0:
-        torch.save({k: v.clone() for k, v in got.items()}, out_path)
+        torch.save({k: v.detach().cpu().clone() for k, v in got.items()}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 

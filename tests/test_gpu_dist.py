@@ -21,20 +21,21 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("bz", [5, 4])
-def test_two_ranks_of_the_real_model_equal_the_single_process_forward(tmp_path, recipe_model, bz):
+@pytest.mark.parametrize("bz,where", [(5, "host"), (4, "host"), (5, "device"), (6, "device")])
+def test_two_ranks_of_the_real_model_equal_the_single_process_forward(tmp_path, recipe_model, bz, where):
     """Two rank processes (started fresh, each on cuda:0) shard a global batch -- bz=5 is UNEVEN (3 + 2
     samples) --, run hands_amd.HandsLight on their shard and all-gather the packed predictions; the gathered
     dict must equal the single-process forward of the global batch BIT FOR BIT (samples are independent and
-    every kernel's summation order is batch-size invariant)."""
+    every kernel's summation order is batch-size invariant).  "device": the predictions stay on the GPU and the
+    gather runs on its own stream behind the forward's asynchronous tail (the path RCCL takes on a multi-GPU node)."""
     out_path = str(tmp_path / "gathered.pt")
     port = _free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HANDS_SYNTHETIC_MANO="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out_path, str(bz), "11"],
-                                      env=env))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out_path, str(bz), "11",
+                                       where], env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
     got = torch.load(out_path)
@@ -54,7 +55,7 @@ def test_bench_launcher_starts_its_own_ranks():
     that way) and print ONE line with n_gpus = 2.  Dry run of that path on the 1-GPU box: both ranks share
     cuda:0 and gather through gloo (HANDS_BENCH_SHARE_GPU / HANDS_BENCH_BACKEND; never set by the driver)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    env.update(HANDS_BENCH_SHARE_GPU="1", HANDS_BENCH_BACKEND="gloo")
+    env.update(HANDS_BENCH_SHARE_GPU="1", HANDS_BENCH_BACKEND="gloo", HANDS_BENCH_GLOO_DEVICE="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--bz", "8", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
