@@ -279,6 +279,8 @@ class HandsLight(EngineSwitches, nn.Module):
         """Drop the packed weights (shared with every replica): call after writing parameters IN PLACE
         (``load_state_dict`` and ``.to()`` do it themselves; ``apply_recipe`` calls it)."""
         self._holder.invalidate()
+        if any(isinstance(v, torch.Tensor) and v.is_cuda for v in self._ws.values()):
+            torch.cuda.synchronize()      # an asynchronous tail of an earlier forward may still use the workspaces
         self._ws = {}
 
     def _apply(self, fn, *a, **k):
@@ -389,6 +391,10 @@ class HandsLight(EngineSwitches, nn.Module):
     def _buf(self, name, numel, dev):
         t = self._ws.get(name)
         if t is None or t.numel() < numel or t.device != dev:
+            if t is not None and t.is_cuda:
+                # a workspace is being replaced (larger batch): an asynchronous tail or a side stream of an earlier
+                # forward may still be using the old block, which the allocator would hand out again at once
+                torch.cuda.synchronize(t.device)
             t = torch.empty(numel, dtype=torch.float32, device=dev)
             self._ws[name] = t
         return t

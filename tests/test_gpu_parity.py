@@ -672,6 +672,16 @@ def test_async_tail_keeps_stream_semantics(gpu_model):
         assert len(o) == 22 and not o.is_pending
         for k in exp:
             assert torch.equal(o[k], exp[k]), (i, k)
+    # a LARGER batch right after an un-consumed forward makes every workspace grow: the old blocks must not be
+    # recycled under the tail that is still reading them
+    fresh = hands_amd.apply_recipe(hands_amd.HandsLight()).to(DEV).eval()      # no workspace exists yet
+    small = fresh(inputs, meta_info)
+    big_in, big_meta = synthetic_inputs(24, 23, device=DEV)
+    big = fresh(big_in, big_meta)
+    assert small.is_pending and big.is_pending
+    for k in ref:
+        assert torch.equal(small[k], ref[k]), k
+    assert torch.isfinite(big["mano.vertices.r"]).all()
 
 
 def test_forward_vs_oracle_with_flips(recipe_sd, gpu_model):
