@@ -287,8 +287,8 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         if phase == "begin":
             macs = pc.macs_per_pixel * npix
             # algorithmic bytes: input read once + output written once (+ residual read) + weights once
-            if kernel == "stem_pool_kernel":      # RGB0 image in, pooled 64-channel map out
-                nbytes = 4.0 * (npix * 4 * 4 + (npix // 4) * 64 + pc.w.numel())
+            if kernel.startswith("stem_pool"):    # image in (RGB0 NHWC4, or the 3 NCHW planes), pooled 64-channel map out
+                nbytes = 4.0 * (npix * 4 * (3 if "planar" in kernel else 4) + (npix // 4) * 64 + pc.w.numel())
             else:
                 nbytes = 4.0 * (npix * pc.Cout * (2 if has_res else 1) + npix * pc.stride * pc.stride * pc.Cin + pc.w.numel())
             info.append((kernel, pc.Cin, pc.Cout, pc.KH, pc.stride, npix, macs, nbytes))
@@ -329,7 +329,7 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
     traffic, traffic_src = pmc_traffic_per_launch(workload)
     res["roofline"] = {
         "bound": "mfma", "mode": "serial (one HIP stream, every launch alone on the chip)",
-        "kernel": "conv_igemm_f32_kernel" + (" + stem_pool_kernel" if "stem_pool_kernel" in per else ""),
+        "kernel": " + ".join(sorted(per)),
         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
         "traffic": traffic, "traffic_unit": "GB per conv_igemm launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",

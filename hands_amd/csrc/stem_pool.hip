@@ -160,6 +160,135 @@ __global__ void __launch_bounds__(256, 3) stem_pool_kernel(const float4* __restr
   }
 }
 
+
+// ---- planar variant: reads the reference's NCHW image directly, K = 3 planes x 52 (49 taps + 3 pad) = 156 -> 160
+// instead of 49 taps x RGB0 = 196 -> 208: 23 % fewer MFMAs, and the NCHW -> NHWC4 conversion launch disappears.
+// A k-group of four consecutive k is four consecutive taps of ONE colour plane (52 % 4 == 0); their patch offsets
+// come from a 160-entry table built once per workgroup, the four values are gathered with ds_read_b32.
+constexpr int KPL = 52;                           // k per colour plane
+constexpr int KPADP = 160;                        // 3 * 52 = 156, padded to 10 steps of 16
+constexpr int PL_ROW = 40;                        // floats per patch row of one plane (20 even + 19 odd columns + 1)
+constexpr int PL_SIZE = IP_H * PL_ROW;            // one plane of the patch
+
+__global__ void __launch_bounds__(256, 3) stem_pool_planar_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, float* __restrict__ out,
+                                                                  int H, int W, int Hc, int Wc, int Hp, int Wp, int tiles_x,
+                                                                  int tiles_per_img, int act) {
+  __shared__ __attribute__((aligned(16))) float patch[3 * PL_SIZE];           // 16.8 KB
+  __shared__ __attribute__((aligned(16))) float stage[256 * ST_ROW];          // 20.5 KB
+  __shared__ __attribute__((aligned(16))) int tapoff[KPADP];                  // patch offset of k at tap (0,0) origin
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / tiles_per_img;
+  const int t = blockIdx.x - b * tiles_per_img;
+  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  const int cy0 = 2 * PT_H * ty - 1, cx0 = 2 * PT_W * tx - 1;      // first convolution pixel of the tile
+  const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;                  // first input pixel of the patch
+
+  if (tid < KPADP) {
+    const int c = tid / KPL, tp = tid - c * KPL;
+    const int tap = tp < 49 ? tp : 48;            // padded taps have zero weights: any finite value will do
+    const int kh = tap / 7, kw = tap - kh * 7;
+    tapoff[tid] = (c < 3 ? c : 2) * PL_SIZE + kh * PL_ROW + (kw & 1) * IP_EVEN + (kw >> 1);
+  }
+  // ---- input patch -> LDS, one plane after the other (zero outside the image = the convolution's padding) ------
+  const float* img = x + (size_t)b * 3 * H * W;
+  for (int i = tid; i < 3 * IP_H * IP_W; i += 256) {
+    const int c = i / (IP_H * IP_W), r = i - c * (IP_H * IP_W);
+    const int pr = r / IP_W, pc = r - pr * IP_W;
+    const int gy = iy0 + pr, gx = ix0 + pc;
+    float v = 0.f;
+    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = img[((size_t)c * H + gy) * W + gx];
+    patch[c * PL_SIZE + pr * PL_ROW + (pc & 1) * IP_EVEN + (pc >> 1)] = v;
+  }
+  __syncthreads();
+
+  // ---- 256 x 64 x 160 GEMM, 64 rows per wave --------------------------------------------------------------
+  const int half = lane >> 5;
+  int pbase[2];                                   // patch offset of this lane's two pixels at tap (0,0), plane 0
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int p = wave * 64 + j * 32 + (lane & 31);
+    p = p < CT_H * CT_W ? p : 0;                  // the one row past 255: any valid pixel, never used
+    const int cy = p / CT_W, cx = p - cy * CT_W;
+    pbase[j] = 2 * cy * PL_ROW + cx;              // column 2*cx + kw -> parity plane (kw & 1), index cx + (kw >> 1)
+  }
+  const float* wl = w + (size_t)(lane & 31) * KPADP + half * 4;    // + i*32*KPADP + 16*s + 8*kk
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int s = 0; s < KPADP / 16; ++s) {
+    float4 wf[2][2], xf[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int4 to = *reinterpret_cast<const int4*>(&tapoff[16 * s + 8 * kk + 4 * half]);   // this lane's four k
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        xf[j][kk] = make_float4(patch[pbase[j] + to.x], patch[pbase[j] + to.y], patch[pbase[j] + to.z], patch[pbase[j] + to.w]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        wf[i][kk] = *reinterpret_cast<const float4*>(wl + (size_t)i * 32 * KPADP + 16 * s + 8 * kk);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(wf[i][kk], tt), f4e(xf[j][kk], tt), acc[i][j], 0, 0, 0);
+  }
+
+  // ---- pool through LDS, 16 channels per round: identical to stem_pool_kernel --------------------------------
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = r >> 1, q0 = (r & 1) * 2;
+    if (r) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float* dst = stage + (wave * 64 + j * 32 + (lane & 31)) * ST_ROW + half * 4;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        *reinterpret_cast<float4*>(dst + q * 8) =
+            make_float4(acc[i][j][(q0 + q) * 4 + 0], acc[i][j][(q0 + q) * 4 + 1], acc[i][j][(q0 + q) * 4 + 2],
+                        acc[i][j][(q0 + q) * 4 + 3]);
+    }
+    __syncthreads();
+    if (tid < PT_H * PT_W * 4) {
+      const int g = tid & 3, pp = tid >> 2;
+      const int py = pp / PT_W, px = pp - py * PT_W;
+      const int gy = PT_H * ty + py, gx = PT_W * tx + px;
+      if (gy < Hp && gx < Wp) {
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int ly = 2 * py + dy;
+          if ((unsigned)(cy0 + ly) >= (unsigned)Hc) continue;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int lx = 2 * px + dx;
+            if ((unsigned)(cx0 + lx) >= (unsigned)Wc) continue;
+            const float4 v = *reinterpret_cast<const float4*>(stage + (ly * CT_W + lx) * ST_ROW + g * 4);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+          }
+        }
+        const int c = i * 32 + q0 * 8 + g * 4;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+        float4 o;
+        o.x = act_scalar(m.x + bv.x, act); o.y = act_scalar(m.y + bv.y, act);
+        o.z = act_scalar(m.z + bv.z, act); o.w = act_scalar(m.w + bv.w, act);
+        *reinterpret_cast<float4*>(out + (((size_t)b * Hp + gy) * Wp + gx) * 64 + c) = o;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int hands_stem_conv_maxpool_nhwc_f32(const float* x4, const float* w_packed, const float* bias, float* out,
@@ -173,5 +302,19 @@ extern "C" int hands_stem_conv_maxpool_nhwc_f32(const float* x4, const float* w_
   if (nwg > 0x7fffffffLL) return HANDS_EINVAL;
   hipLaunchKernelGGL(stem_pool_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)x4, w_packed, bias, out, H, W, Hc, Wc, Hp, Wp, tiles_x, tiles_y * tiles_x, act);
+  HANDS_LAUNCH_CHECK();
+}
+
+extern "C" int hands_stem_conv_maxpool_nchw_f32(const float* x_nchw, const float* w_planar, const float* bias, float* out,
+                                                int B, int H, int W, int act, hands_stream_t stream) {
+  if (!x_nchw || !w_planar || !bias || !out || B <= 0 || H < 7 || W < 7) return HANDS_EINVAL;
+  if (act != HANDS_ACT_NONE && act != HANDS_ACT_RELU && act != HANDS_ACT_LEAKY_RELU) return HANDS_EINVAL;
+  const int Hc = (H + 6 - 7) / 2 + 1, Wc = (W + 6 - 7) / 2 + 1;
+  const int Hp = (Hc + 2 - 3) / 2 + 1, Wp = (Wc + 2 - 3) / 2 + 1;
+  const int tiles_y = (Hp + PT_H - 1) / PT_H, tiles_x = (Wp + PT_W - 1) / PT_W;
+  const long long nwg = (long long)B * tiles_y * tiles_x;
+  if (nwg > 0x7fffffffLL) return HANDS_EINVAL;
+  hipLaunchKernelGGL(stem_pool_planar_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, x_nchw, w_planar, bias,
+                     out, H, W, Hc, Wc, Hp, Wp, tiles_x, tiles_y * tiles_x, act);
   HANDS_LAUNCH_CHECK();
 }

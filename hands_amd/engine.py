@@ -135,6 +135,19 @@ class ConvEngine:
             hook("end", pc, B * Hc * Wc, stream, False, "stem_pool_kernel")
         return Hc, Wc
 
+    def stem_pool_nchw(self, L, pc, x, x_off, out, out_off, B, H, W, act, stream):
+        """The same stem reading the NCHW image in place (hands_stem_conv_maxpool_nchw_f32): K = 3 planes x 52 =
+        160 instead of 208, and no NHWC4 copy of the input.  ``pc`` is the planar packing (k = plane * 52 + tap)."""
+        Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        hook = self.hook
+        if hook is not None:
+            hook("begin", pc, B * Hc * Wc, stream, False, "stem_pool_planar_kernel")
+        check(L.hands_stem_conv_maxpool_nchw_f32(ptr(x, x_off), ptr(pc.w), ptr(pc.bias), ptr(out, out_off), B, H, W, int(act),
+                                                 stream), "hands_stem_conv_maxpool_nchw_f32")
+        if hook is not None:
+            hook("end", pc, B * Hc * Wc, stream, False, "stem_pool_planar_kernel")
+        return Hc, Wc
+
 
 DEFAULT_ENGINE = ConvEngine()
 

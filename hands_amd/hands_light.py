@@ -294,6 +294,10 @@ class HandsLight(EngineSwitches, nn.Module):
         P = {}
         w, b = fold_bn(cpu(net.conv1.weight), *bnp(net.bn1))
         P["stem"] = pack_conv(w, b, 2, 3, dev, cin_pad_to=4)
+        # planar form for hands_stem_conv_maxpool_nchw_f32: k = plane * 52 + tap (49 taps + 3 zero columns per plane)
+        col = [c * 52 + t for c in range(3) for t in range(49)]
+        P["stem_planar"] = pack_linear(w.reshape(64, 147), b, dev, col_index=col, k_total=160)
+        P["stem_planar"].macs_per_pixel = 64 * 147
         blocks = []
         for li in range(1, 5):
             for blk in getattr(net, f"layer{li}"):
@@ -426,11 +430,12 @@ class HandsLight(EngineSwitches, nn.Module):
             cur, nxt = dst, cur
         return H, W
 
-    def _trunk(self, L, P, x4, B, res_in, stream, tag, cap_B, out=None, x_off=0, out_off=0):
-        """ResNet-50 trunk on an NHWC4 batch; returns (B,7,7,2048) features (flat tensor).
+    def _trunk(self, L, P, segs, B, res_in, stream, tag, cap_B, out=None, out_off=0):
+        """ResNet-50 trunk on B images given as NCHW segments ``[(tensor, first image, n images), ...]`` (the
+        reference's input layout, read in place); returns (B,7,7,2048) features (flat tensor).
         (Running stem + layer1 + layer2 per sub-batch of 32-128 images, to keep their HBM-bound 1x1 layers'
         tensors inside the 256 MB Infinity Cache, was measured 1-18 % SLOWER than whole-job launches.)"""
-        dev = x4.device
+        dev = segs[0][0].device
         per = 112 * 112 * 64 * (res_in * res_in) // (224 * 224) + 64      # floats per image of the largest map
         cap = cap_B * per
         a = self._buf("trunk_a_" + tag, cap, dev); b = self._buf("trunk_b_" + tag, cap, dev)
@@ -438,12 +443,21 @@ class HandsLight(EngineSwitches, nn.Module):
         ds = self._buf("trunk_ds_" + tag, cap, dev)
         Hs, Ws = (res_in - 1) // 2 + 1, (res_in - 1) // 2 + 1                # stem conv map
         Hp, Wp = (Hs + 2 - 3) // 2 + 1, (Ws + 2 - 3) // 2 + 1                # after the max-pool
-        if self.engine.fuse_stem_pool:
-            # conv1 + bn1 + relu + maxpool in one kernel: the 112x112x64 map never reaches HBM
-            self.engine.stem_pool(L, P["stem"], x4, x_off, b, B, res_in, res_in, 1, stream)
-        else:
-            self.engine.conv(L, P["stem"], x4, B, res_in, res_in, a, True, stream, x_off=x_off)
-            check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(b), B, Hs, Ws, 64, stream), "maxpool")
+        img_floats = 3 * res_in * res_in
+        done = 0
+        for src, first, n in segs:
+            if self.engine.fuse_stem_pool:
+                # conv1 + bn1 + relu + maxpool in one kernel straight from the NCHW image: neither the NHWC copy
+                # of the input nor the 112x112x64 map ever reaches HBM
+                self.engine.stem_pool_nchw(L, P["stem_planar"], src, first * img_floats, b, done * Hp * Wp * 64, n,
+                                           res_in, res_in, 1, stream)
+            else:
+                x4 = self._buf("trunk_x4_" + tag, cap_B * res_in * res_in * 4, dev)
+                check(L.hands_nchw3_to_nhwc4_f32(ptr(src, first * img_floats), ptr(x4), n, res_in, res_in, stream), "nchw->nhwc4")
+                self.engine.conv(L, P["stem"], x4, n, res_in, res_in, a, True, stream)
+                check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(b, done * Hp * Wp * 64), n, Hs, Ws, 64, stream), "maxpool")
+            done += n
+        assert done == B
         feat = out if out is not None else self._buf("feat_" + tag, B * 49 * P["blocks"][-1]["c3"].Cout, dev)
         H, W = self._blocks(L, P["blocks"], b, a, t1, t2, ds, B, Hp, Wp, stream, feat, out_off)
         return feat, H, W
@@ -489,34 +503,32 @@ class HandsLight(EngineSwitches, nn.Module):
                 prev_tail = self._ws.get(f"tail_done{q}")
                 if prev_tail is not None:
                     main.wait_event(prev_tail)
-        x4g = buf("x4g", bz * res * res * 4)
-        x4 = buf("x4", B2 * res * res * 4)
         featg = buf(f"feat_g{par}", bz * 49 * F)
         feath = buf(f"feat_h{par}", B2 * 49 * F)
         gch, hch = self.trunk_chunks if self.engine.overlap else (1, 1)
         gch, hch = max(1, min(gch, bz)), max(1, min(hch, B2))
-        jobs = []   # (weights, images, x4 buffer, first sample, n samples, out buffer, is_global)
+        jobs = []   # (weights, NCHW segments [(tensor, first image, n)], first row of the job, n images, out buffer)
         for c in range(gch):
             lo, hi = c * bz // gch, (c + 1) * bz // gch
-            jobs.append((P["backbone"], x4g, lo, hi - lo, featg, True))
-        for c in range(hch):
+            jobs.append((P["backbone"], [(img, lo, hi - lo)], lo, hi - lo, featg))
+        for c in range(hch):       # rows [0, bz) of the hand batch are the right crops, [bz, 2 bz) the left crops
             lo, hi = c * B2 // hch, (c + 1) * B2 // hch
-            jobs.append((P["hand_backbone"], x4, lo, hi - lo, feath, False))
-        check(L.hands_nchw3_to_nhwc4_f32(ptr(img), ptr(x4g), bz, res, res, stream), "nchw->nhwc4")
-        check(L.hands_nchw3_to_nhwc4_f32(ptr(r_img), ptr(x4), bz, res, res, stream), "nchw->nhwc4")
-        check(L.hands_nchw3_to_nhwc4_f32(ptr(l_img), ptr(x4, bz * res * res * 4), bz, res, res, stream),
-              "nchw->nhwc4")
+            segs = []
+            if lo < bz:
+                segs.append((r_img, lo, min(hi, bz) - lo))
+            if hi > bz:
+                segs.append((l_img, max(lo, bz) - bz, hi - max(lo, bz)))
+            jobs.append((P["hand_backbone"], segs, lo, hi - lo, feath))
         ev0 = torch.cuda.Event()
         ev0.record(main)
         fh = fw = 7
         done = []
-        for ji, (Pt, xb, lo, n, ob, is_g) in enumerate(jobs):
+        for ji, (Pt, segs, lo, n, ob) in enumerate(jobs):
             # the largest job (last) stays on the caller's stream
             st = main if (ji == len(jobs) - 1 or not self.engine.overlap) else self._side_stream(dev, f"side{ji}")
             if st is not main:
                 st.wait_event(ev0)
-            _, fh, fw = self._trunk(L, Pt, xb, n, res, st.cuda_stream, f"j{ji}", n, out=ob,
-                                    x_off=lo * res * res * 4, out_off=lo * 49 * F)
+            _, fh, fw = self._trunk(L, Pt, segs, n, res, st.cuda_stream, f"j{ji}", n, out=ob, out_off=lo * 49 * F)
             if st is not main:
                 ev = torch.cuda.Event()
                 ev.record(st)

@@ -130,6 +130,14 @@ int hands_conv1x1_dual_nhwc_f32(const hands_conv_desc* d, const float* in, const
 int hands_stem_conv_maxpool_nhwc_f32(const float* x4, const float* w_packed, const float* bias, float* out,
                                      int B, int H, int W, int act, hands_stream_t stream);
 
+/* The same stem reading the reference's NCHW image (B,3,H,W) directly -- no NHWC4 conversion launch -- with the
+ * contraction ordered (colour plane, kh, kw): w_planar is [128][160] row-major, k = plane * 52 + kh * 7 + kw (taps
+ * 49..51 of each plane and k >= 156 zero), i.e. hands_pack_linear_f64 of the folded (64, 147) weight with
+ * col_index[c * 49 + tap] = c * 52 + tap, k_total = 160.  K = 160 instead of 208: 23 % fewer MFMAs.  Same result as
+ * hands_stem_conv_maxpool_nhwc_f32 up to the fp32 rounding of a different summation order. */
+int hands_stem_conv_maxpool_nchw_f32(const float* x_nchw, const float* w_planar, const float* bias, float* out,
+                                     int B, int H, int W, int act, hands_stream_t stream);
+
 /* NCHW (B,3,H,W) image batch -> NHWC with C padded to 4 (4th channel = 0).
  * Replaces the implicit layout of inputs["img"|"r_img"|"l_img"] (model.py:188,238-239). */
 int hands_nchw3_to_nhwc4_f32(const float* in, float* out, int B, int H, int W, hands_stream_t stream);

@@ -241,6 +241,40 @@ def test_fused_stem_maxpool_is_bit_identical(shape, act):
     assert (got.cpu().permute(0, 3, 1, 2).double() - t).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 224, 224), (3, 64, 80), (1, 57, 43), (2, 256, 256)])
+@pytest.mark.parametrize("act", [1, 3])
+def test_planar_stem_reads_nchw_and_matches(shape, act):
+    """hands_stem_conv_maxpool_nchw_f32: the stem straight from the NCHW image, contraction ordered (plane, kh, kw)
+    (K = 160 instead of 208).  Against torch fp64 and against the NHWC4 stem (same math, other summation order)."""
+    from hands_amd.packing import pack_linear
+    B, H, W = shape
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(B * H + W + act)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    bias = torch.randn(64, generator=g)
+    x = torch.randn(B + 1, 3, H, W, generator=g)
+    col = [c * 52 + t for c in range(3) for t in range(49)]
+    pp = pack_linear(w.reshape(64, 147), bias, DEV, col_index=col, k_total=160)
+    assert pp.w.shape == (128, 160) and torch.all(pp.w[:, 49:52] == 0) and torch.all(pp.w[:, 156:] == 0)
+    xd = x.to(DEV).contiguous()
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+    got = torch.full((B, Hp, Wp, 64), float("nan"), device=DEV)
+    check(L.hands_stem_conv_maxpool_nchw_f32(ptr(xd, 3 * H * W), ptr(pp.w), ptr(pp.bias), ptr(got), B, H, W, act, _stream()),
+          "planar stem")                                    # image offset 1: the segment form the trunk uses
+    pc = pack_conv(w, bias, 2, 3, DEV, cin_pad_to=4)
+    x4 = F.pad(_nhwc(x[1:]), (0, 1)).to(DEV).contiguous()
+    old = torch.full((B, Hp, Wp, 64), float("nan"), device=DEV)
+    check(L.hands_stem_conv_maxpool_nhwc_f32(ptr(x4), ptr(pc.w), ptr(pc.bias), ptr(old), B, H, W, act, _stream()), "nhwc stem")
+    torch.cuda.synchronize()
+    t = F.conv2d(x[1:].double(), w.double(), bias.double(), stride=2, padding=3)
+    t = F.relu(t) if act == 1 else F.leaky_relu(t, 0.01)
+    t = F.max_pool2d(t, 3, 2, 1)
+    assert (got.cpu().permute(0, 3, 1, 2).double() - t).abs().max().item() < 2e-5
+    assert (got - old).abs().max().item() < 2e-5
+    assert L.hands_stem_conv_maxpool_nchw_f32(None, ptr(pp.w), ptr(pp.bias), ptr(got), B, H, W, act, _stream()) == 10001
+
+
 def test_layout_pool_kernels():
     L = _lib.lib()
     g = torch.Generator().manual_seed(5)
