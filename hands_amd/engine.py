@@ -89,7 +89,8 @@ class ConvEngine:
                                                    ptr(res, res_off) if res is not None else None, ptr(out, out_off),
                                                    S, ptr(ws), ws.numel(), stream), "hands_conv2d_nhwc_splitk_n_f32")
         elif self.math == "fp32" and ((not self.overlap) if self.stream_k == "auto" else self.stream_k) and \
-                L.hands_conv2d_streamk_grid(C.byref(d)) > 0:
+                L.hands_conv2d_streamk_grid(C.byref(d)) > 0 and not torch.cuda.is_current_stream_capturing():
+            # (not under hipGraph capture: the zero-filled workspace of a new stream cannot be set up inside one)
             key = (x.device, stream)
             sk = self._sk_ws.get(key)
             if sk is None:

@@ -617,6 +617,17 @@ def test_graphed_forward_is_bit_identical(gpu_model):
     bad, meta3 = synthetic_inputs(3, 0, device=DEV)
     with pytest.raises(ValueError):
         gf(bad, meta3)
+    # one-stream mode (stream-K would want a zeroed workspace: not under capture) captures and replays too
+    import copy
+    serial = hands_amd.apply_recipe(hands_amd.HandsLight()).to(DEV).eval()
+    serial.overlap_trunks = False
+    inputs, meta_info = synthetic_inputs(2, 0, device=DEV)
+    eager = {k: v.clone() for k, v in serial(inputs, meta_info).items()}
+    gs = GraphedForward(serial, inputs, meta_info)
+    got = gs(inputs, meta_info)
+    torch.cuda.synchronize()
+    for k in eager:
+        assert torch.equal(got[k], eager[k]), k
 
 
 def test_replica_on_a_second_stream(gpu_model):
