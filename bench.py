@@ -334,6 +334,8 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
         "traffic": traffic, "traffic_unit": "GB per conv_igemm launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)",
         "traffic_source": traffic_src,
+        "traffic_over_algorithmic": (round(traffic / (per["conv_igemm_f32_kernel"]["bytes"] / per["conv_igemm_f32_kernel"]["launches"] / 1e9), 3)
+                                     if traffic and "conv_igemm_f32_kernel" in per else None),
         "launches_per_step": launches, "kernel_ms_per_step": round(k_ms, 3),
         "step_ms_same_mode": round(ser_ms, 3), "event_bracket_overhead_us": round(ev_overhead_ms * 1e3, 2),
         "algorithmic_gflop_per_sample": round(k_flop / bz / 1e9, 3), "kernels": kernels}
