@@ -31,7 +31,7 @@ if os.environ.get('HANDS_BENCH_ONE'):
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 eng = ConvEngine()
 eng.math = sys.argv[2] if len(sys.argv) > 2 else "fp32"
-eng.stream_k = False
+eng.stream_k = os.environ.get("HANDS_STREAMK") == "1"
 L = _lib.lib()
 dev = "cuda"
 stream = torch.cuda.current_stream().cuda_stream
