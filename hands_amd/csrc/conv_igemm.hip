@@ -97,6 +97,62 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Epilogue of a FULL tile (no row / channel predicates) with act in {NONE, RELU}: the common case of every trunk
+// layer, as straight-line code -- 16 LDS writes, then per output row one LDS read, packed bias (+ residual) adds,
+// the clamp, one 64-bit address add and the store.  The general path below (runtime activation switch, per-row
+// predicates) executes ~4x the instructions, and a workgroup in its epilogue holds a wave slot per SIMD without
+// feeding the matrix pipe: with K = 256 a tile spent 12 of its 72 us there (tools/prof_tile.py).
+// Same arithmetic as the general path: (acc + bias) + residual, then max(., 0).
+constexpr int EROW = 68;                            // 64 channels + 4 pad floats (17 slots: odd)
+template <bool RELU, bool RES>
+__device__ __forceinline__ void epilogue_full(const f32x16 (&acc)[2][2], float* sE, int lane, const float* bias_p,
+                                              const char* res_u, int res_ps, char* out_u, int out_ps) {
+  // res_u / out_u: wave-uniform byte address of this wave's (pixel 0, channel 0); the lane part is one 32-bit
+  // offset, so every access is "scalar base + vector offset" and the row stepping costs no vector instructions
+  const int half = lane >> 5;
+  float* wr = sE + (lane & 31) * EROW + half * 4;
+  const float* rd = sE + (lane >> 4) * EROW + (lane & 15) * 4;
+  const uint32_t o_off = (uint32_t)((lane >> 4) * out_ps + (lane & 15) * 4) * 4u;
+  const uint32_t r_off = (uint32_t)((lane >> 4) * res_ps + (lane & 15) * 4) * 4u;
+  const float4 bv4 = *reinterpret_cast<const float4*>(bias_p);
+  const f32x2 b01 = {bv4.x, bv4.y}, b23 = {bv4.z, bv4.w};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(wr + i * 32 + q * 8) =
+            make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+    float4 rv[RES ? 8 : 1];
+    if constexpr (RES) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        rv[r] = *reinterpret_cast<const float4*>(res_u + (size_t)(j * 32 + 4 * r) * (size_t)res_ps * 4 + r_off);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float4 t = *reinterpret_cast<const float4*>(rd + 4 * r * EROW);
+      f32x2 v01 = {t.x, t.y}, v23 = {t.z, t.w};
+      v01 = v01 + b01;
+      v23 = v23 + b23;
+      if constexpr (RES) {
+        const f32x2 r01 = {rv[r].x, rv[r].y}, r23 = {rv[r].z, rv[r].w};
+        v01 = v01 + r01;
+        v23 = v23 + r23;
+      }
+      float4 v = make_float4(v01.x, v01.y, v23.x, v23.y);
+      if constexpr (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(out_u + (size_t)(j * 32 + 4 * r) * (size_t)out_ps * 4 + o_off) = v;
+      // rows in pairs: without the fence the scheduler hoists all eight LDS reads (+32 live registers on top of
+      // the 64 accumulators and 32 residual values: 160+ VGPRs, 3 waves per SIMD instead of 4)
+      if (r & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 // MODE 0: any convolution with Cin % 16 == 0 (k-steps ordered channel chunk, kh, kw); 1: the stem (Cin == 4, one filter tap per 16-byte chunk);
 // 2: two 1x1 convolutions summed into one output (k < K0 from `in`, the rest from `in2` sampled with
 //    its own stride) -- the last conv of a bottleneck fused with the block's downsample branch.
@@ -344,13 +400,26 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
               make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
     return;
   }
-  constexpr int EROW = 68;                          // 64 channels + 4 pad floats (17 slots: odd)
   float* sE = lds + wave * (32 * EROW);
   const int half = lane >> 5;
   const int c4 = lane & 15;                         // this lane's 4-channel group in the read-back
   const int n_lane = n0 + wn * 64 + c4 * 4;
   const bool n_ok = n_lane < a.N;
   const bool part = a.ksplit > 1;                   // split-K: raw partial sums, reduced by splitk_reduce_kernel
+  if (!part && a.relu <= HANDS_ACT_RELU && m0 + BM <= a.M && n0 + BN <= a.N) {      // (uniform) full tile, plain epilogue
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int mw = m0 + (wave_u / WAVES_N) * 64, nw = n0 + (wave_u % WAVES_N) * 64;
+    char* ou = reinterpret_cast<char*>(a.out) + ((size_t)mw * a.out_ps + nw) * 4;
+    const char* ru = reinterpret_cast<const char*>(a.res) + ((size_t)mw * a.res_ps + nw) * 4;
+    if (a.relu == HANDS_ACT_RELU) {
+      if (a.res != nullptr) epilogue_full<true, true>(acc, sE, lane, a.bias + n_lane, ru, a.res_ps, ou, a.out_ps);
+      else                  epilogue_full<true, false>(acc, sE, lane, a.bias + n_lane, ru, a.res_ps, ou, a.out_ps);
+    } else {
+      if (a.res != nullptr) epilogue_full<false, true>(acc, sE, lane, a.bias + n_lane, ru, a.res_ps, ou, a.out_ps);
+      else                  epilogue_full<false, false>(acc, sE, lane, a.bias + n_lane, ru, a.res_ps, ou, a.out_ps);
+    }
+    return;
+  }
   const float4 bv = part ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(a.bias + n_lane);
   const bool has_res = !part && a.res != nullptr;
   const int act = part ? HANDS_ACT_NONE : a.relu;

@@ -28,6 +28,9 @@ SHAPES = [  # B, Cin, H, Cout, k, stride, pad, residual
 ]
 if os.environ.get('HANDS_BENCH_ONE'):
     SHAPES = SHAPES[:1]
+if os.environ.get('HANDS_BENCH_SHAPES'):      # "B,Cin,H,Cout,k,stride,pad,res;..."
+    SHAPES = [tuple(int(v) for v in t.split(',')[:7]) + (t.split(',')[7] == '1',)
+              for t in os.environ['HANDS_BENCH_SHAPES'].split(';') if t]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 eng = ConvEngine()
 eng.math = sys.argv[2] if len(sys.argv) > 2 else "fp32"
