@@ -24,6 +24,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // nn.GELU() (exact, erf form): x * 0.5 * (1 + erf(x / sqrt(2)))
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -196,6 +197,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
   int x_hi0[A_ROWS], x_wi0[A_ROWS];
   bool x_ok[A_ROWS];
   int x_base2[DUAL ? A_ROWS : 1];
+  // MODE 0 (padded convolution): per row ONE validity word (bit kh: row hi0 + kh inside the image, bit 16 + kw:
+  // column wi0 + kw inside; 0 for rows past M) and a byte offset relative to a wave-uniform base.  A k-step then
+  // costs and / compare / add / select per row, and the load is a raw-buffer load whose out-of-range offset
+  // (0x80000000 >= num_records) returns zeros in hardware: no predicated branches, no zero fill in registers
+  uint32_t x_mask[MODE == 0 ? A_ROWS : 1];
+  int x_offb[MODE == 0 ? A_ROWS : 1];
+  int x_b[A_ROWS];
   const int HoWo = a.Ho * a.Wo;
 #pragma unroll
   for (int i = 0; i < A_ROWS; ++i) {
@@ -206,6 +214,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
     const int rem = mm - b * HoWo;
     const int ho = rem / a.Wo;
     const int wo = rem - ho * a.Wo;
+    x_b[i] = b;
     x_hi0[i] = ho * a.stride - a.pad;
     x_wi0[i] = wo * a.stride - a.pad;
     x_base[i] = ((b * a.H + x_hi0[i]) * a.W + x_wi0[i]) * a.in_ps;
@@ -213,9 +222,44 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
       x_base2[i] = ((b * a.H2 + ho * a.stride2) * a.W2 + wo * a.stride2) * a.in2_ps;
     }
   }
-  const float* wrow[W_ROWS];
+  __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)0x80000000u, 0x00020000);
+  if constexpr (MODE == 0) {
+    // base = first image this wave stages (its lane 0, i = 0 holds the smallest row); rows past M sit on image 0 and
+    // have an empty mask, so their (possibly negative) offsets are never used
+    const int b_w = __builtin_amdgcn_readfirstlane(x_b[0]);
+    x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in) + (size_t)b_w * a.H * a.W * a.in_ps, 0,
+                                               (int)0x80000000u, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < W_ROWS; ++i) wrow[i] = a.w + (size_t)(n0 + srow + 64 * i) * a.Kpad + chunk * 4;
+    for (int i = 0; i < A_ROWS; ++i) {
+      const int hb = max(0, -x_hi0[i]), he = min(a.KH, a.H - x_hi0[i]);
+      const int wb = max(0, -x_wi0[i]), we = min(a.KW, a.W - x_wi0[i]);
+      const uint32_t hm = he > hb ? ((1u << he) - 1u) & ~((1u << hb) - 1u) : 0u;
+      const uint32_t wm = we > wb ? ((1u << we) - 1u) & ~((1u << wb) - 1u) : 0u;
+      x_mask[i] = (x_ok[i] && hm != 0u && wm != 0u) ? (hm | (wm << 16)) : 0u;
+      x_offb[i] = (((((x_b[i] - b_w) * a.H + x_hi0[i]) * a.W + x_wi0[i]) * a.in_ps) + chunk * 4) * 4;
+    }
+  }
+  // MODE 2 (pointwise / two-source): byte offsets relative to the first row this wave stages, one descriptor per
+  // source; the k position is the instruction's scalar offset, so a k-step has no address arithmetic at all
+  int x_off1[DUAL ? A_ROWS : 1], x_off2[DUAL ? A_ROWS : 1];
+  __amdgpu_buffer_rsrc_t x_rsrc2 = x_rsrc;
+  if constexpr (DUAL) {
+    const int base1 = __builtin_amdgcn_readfirstlane(x_base[0]);
+    const int base2 = __builtin_amdgcn_readfirstlane(x_base2[0]);
+    x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in) + base1, 0, (int)0x80000000u, 0x00020000);
+    x_rsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in2) + base2, 0, (int)0x80000000u, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {      // rows past M read the wave's first row (their outputs are never stored)
+      x_off1[i] = x_ok[i] ? (x_base[i] - base1 + chunk * 4) * 4 : chunk * 16;
+      x_off2[i] = x_ok[i] ? (x_base2[i] - base2 + chunk * 4) * 4 : chunk * 16;
+    }
+  }
+  // weights: rows of this tile relative to its first row, k position as the scalar offset
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w) + (size_t)n0 * a.Kpad, 0, (int)0x80000000u, 0x00020000);
+  int w_offb[W_ROWS];
+#pragma unroll
+  for (int i = 0; i < W_ROWS; ++i) w_offb[i] = ((srow + 64 * i) * a.Kpad + chunk * 4) * 4;
 
   // staging registers (explicit scalars-of-float4: arrays captured by lambdas ended up in scratch)
   float4 xr[A_ROWS], wr[W_ROWS];
@@ -243,20 +287,23 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
       /* past M were given the address of row 0 above: load unconditionally (their outputs are     */ \
       /* never stored), which keeps the k-loop free of branches                                    */ \
       const bool second = (KT) * BK >= a.K0;                                                        \
-      const float* dsrc = second ? a.in2 - a.K0 : a.in;                                             \
-      _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i)                                            \
-        xr[i] = *reinterpret_cast<const float4*>(dsrc + ((second ? x_base2[i] : x_base[i]) + (KT) * BK + chunk * 4)); \
+      const int soff = ((KT) * BK - (second ? a.K0 : 0)) * 4;                                       \
+      _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) {                                          \
+        const u32x4 ld = second ? __builtin_amdgcn_raw_buffer_load_b128(x_rsrc2, x_off2[i], soff, 0) \
+                                : __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, x_off1[i], soff, 0);  \
+        xr[i] = make_float4(__uint_as_float(ld.x), __uint_as_float(ld.y), __uint_as_float(ld.z), __uint_as_float(ld.w)); \
+      }                                                                                             \
     } else {                                                                                        \
       /* k order (chunk of cw channels, kh, kw, 16-channel step): the taps of one chunk re-read the  */ \
       /* same 64-128 B of every pixel within a few k-steps, while the lines are still in the XCD's  */ \
       /* L2; with taps outermost every tap pass streamed the whole tile again from HBM (8.6x)       */ \
       const bool kvalid = c0 < a.Cin;          /* false only in caller-added zero padding of K */    \
-      const int toff = (kh * a.W + kw) * a.in_ps + c0 + chunk * 4;                                  \
+      const uint32_t sel = kvalid ? ((1u << kh) | (0x10000u << kw)) : 0x80000000u;  /* bit 31 is never in a mask */ \
+      const int toffb = ((kh * a.W + kw) * a.in_ps + c0) * 4;                                       \
       _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) {                                          \
-        const bool ok = kvalid && x_ok[i] && (unsigned)(x_hi0[i] + kh) < (unsigned)a.H &&           \
-                        (unsigned)(x_wi0[i] + kw) < (unsigned)a.W;                                  \
-        xr[i] = ok ? *reinterpret_cast<const float4*>(a.in + (x_base[i] + toff))                    \
-                   : make_float4(0.f, 0.f, 0.f, 0.f);                                               \
+        const bool ok = (x_mask[i] & sel) == sel;                                                   \
+        const u32x4 ld = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? x_offb[i] + toffb : (int)0x80000000u, 0, 0); \
+        xr[i] = make_float4(__uint_as_float(ld.x), __uint_as_float(ld.y), __uint_as_float(ld.z), __uint_as_float(ld.w)); \
       }                                                                                             \
       woff = kvalid ? (kh * a.KW + kw) * a.Cin + c0 : (KT) * BK;                                    \
       c0 += BK;                                                                                     \
@@ -266,8 +313,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
       }                                                                                             \
     }                                                                                               \
     if constexpr (MODE != 0) woff = (KT) * BK;                                                      \
-    _Pragma("unroll") for (int i = 0; i < W_ROWS; ++i)                                              \
-      wr[i] = *reinterpret_cast<const float4*>(wrow[i] + woff);                                     \
+    _Pragma("unroll") for (int i = 0; i < W_ROWS; ++i) {                                            \
+      const u32x4 ld = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_offb[i], woff * 4, 0);        \
+      wr[i] = make_float4(__uint_as_float(ld.x), __uint_as_float(ld.y), __uint_as_float(ld.z), __uint_as_float(ld.w)); \
+    }                                                                                               \
   } while (0)
 
 #define STORE_TILES(BUF)                                                                            \
@@ -668,7 +717,15 @@ bool conv_geometry_ok(const hands_conv_desc* d) {
   if (d->H + 2 * d->pad < d->KH || d->W + 2 * d->pad < d->KW) return false;
   if (d->Ho > (d->H + 2 * d->pad - d->KH) / d->stride + 1 || d->Wo > (d->W + 2 * d->pad - d->KW) / d->stride + 1) return false;
   if ((long long)d->B * d->H * d->W * d->in_pix_stride >= (1LL << 31)) return false;
-  if ((long long)d->B * d->Ho * d->Wo >= (1LL << 31) / (d->out_pix_stride > 0 ? d->out_pix_stride : 1)) return false;
+  if (d->Cin != 4) {
+    // 32-bit byte offsets relative to the first image / row a wave stages (its 256 rows reach at most
+    // 256 / (Ho * Wo) + 1 images further) and to the first weight row of a tile
+    const long long imgs = 256 / ((long long)d->Ho * d->Wo) + 2;
+    if (imgs * d->H * d->W * d->in_pix_stride * 4 >= (1LL << 31)) return false;
+    if (256LL * d->Kpad * 4 >= (1LL << 31)) return false;
+    // padded-convolution k-loop: tap validity is a 15 + 15 bit word per row
+    if (!(d->KH == 1 && d->KW == 1 && d->pad == 0) && (d->KH > 15 || d->KW > 15)) return false;
+  }
   return true;
 }
 
@@ -766,6 +823,12 @@ extern "C" int hands_conv1x1_dual_nhwc_f32(const hands_conv_desc* d, const float
   if ((long long)d->B * d->H * d->W * d->in_pix_stride >= (1LL << 31) ||
       (long long)d->B * H2 * W2 * in2_pix_stride >= (1LL << 31))
     return HANDS_EINVAL;
+  {   // 32-bit byte offsets relative to the first row a wave stages (see conv_geometry_ok)
+    const long long imgs = 256 / ((long long)d->Ho * d->Wo) + 2;
+    if (imgs * d->H * d->W * d->in_pix_stride * 4 >= (1LL << 31) || imgs * H2 * W2 * in2_pix_stride * 4 >= (1LL << 31) ||
+        256LL * d->Kpad * 4 >= (1LL << 31))
+      return HANDS_EINVAL;
+  }
   ConvArgs a;
   a.in = in; a.w = w_packed; a.bias = bias; a.res = nullptr; a.out = out;
   a.M = d->B * d->Ho * d->Wo; a.N = d->Cout; a.Kpad = d->Kpad;

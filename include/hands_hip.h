@@ -46,6 +46,10 @@ const char* hands_error_string(int code);
  * (kh, kw, cin), Kpad = round_up(KH*KW*Cin, 16) zero-filled, Cout_pad = round_up(Cout, 128)
  * zero-filled.  bias has Cout_pad entries.  Cin % 4 == 0 and Cout % 4 == 0 are required;
  * Cin % 16 == 0 unless Cin == 4 (the RGB0 stem).
+ * Limits (HANDS_EINVAL beyond them; every layer of the three models is far inside): for Cin != 4, padded
+ * convolutions take KH, KW <= 15 (tap validity is one 15 + 15 bit word per output pixel), Kpad < 2^21, and
+ * (256 / (Ho*Wo) + 2) * H * W * in_pix_stride * 4 < 2^31 (the kernels address a tile's inputs with 32-bit
+ * byte offsets from the first image the tile touches).
  * --------------------------------------------------------------------------------------------- */
 typedef struct hands_conv_desc {
   int32_t B, H, W, Cin;      /* input  (B,H,W,Cin) */
