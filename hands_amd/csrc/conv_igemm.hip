@@ -205,11 +205,19 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
   int x_offb[MODE == 0 ? A_ROWS : 1];
   int x_b[A_ROWS];
   const int HoWo = a.Ho * a.Wo;
+  // plain pointwise layer (one source, stride 1): the input pixel IS the output pixel, no (b, ho, wo) decomposition
+  const bool same_pixel = DUAL && a.K0 >= a.Kpad && a.stride == 1 && a.H == a.Ho && a.W == a.Wo;
 #pragma unroll
   for (int i = 0; i < A_ROWS; ++i) {
     const int m = m0 + srow + 64 * i;
     x_ok[i] = m < a.M;
     const int mm = x_ok[i] ? m : 0;
+    if (same_pixel) {
+      x_b[i] = 0; x_hi0[i] = 0; x_wi0[i] = 0;
+      x_base[i] = mm * a.in_ps;
+      if constexpr (DUAL) x_base2[i] = 0;
+      continue;
+    }
     const int b = mm / HoWo;
     const int rem = mm - b * HoWo;
     const int ho = rem / a.Wo;
@@ -380,7 +388,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
 
 #define COMPUTE_STEP(BUF)                                                                           \
   do {                                                                                              \
-    if constexpr (PREC == 0) {                                                                      \
+    if constexpr (PREC == 0) {                                                               \
       float4 wf[2][2], xf[2][2]; /* [32-row block][kk] */                                           \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                            \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                             \
