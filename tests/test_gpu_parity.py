@@ -109,6 +109,65 @@ def test_conv_igemm_random_shapes(case):
     test_conv_igemm_vs_torch(case)
 
 
+ADDRESSING_CASES = [
+    # the k-loop addresses a tile's inputs with 32-bit byte offsets from the first image a wave touches and masks
+    # taps with one validity word per output pixel: tiles spanning many tiny images, 1x1 maps with padding, a 1x1
+    # kernel with padding, a strided pointwise layer on 3x3 maps, a 5x5 kernel on maps smaller than the kernel
+    (300, 32, 2, 2, 64, 3, 1, 1, True, False),
+    (700, 16, 1, 1, 128, 3, 1, 1, False, False),
+    (2, 16, 5, 5, 20, 1, 1, 1, True, False),
+    (130, 48, 3, 3, 132, 1, 2, 0, True, False),
+    (67, 16, 3, 4, 68, 5, 1, 2, True, True),
+    (9, 32, 13, 7, 64, 3, 3, 1, False, False),
+]
+
+
+@pytest.mark.parametrize("case", ADDRESSING_CASES)
+def test_conv_igemm_addressing_edges(case):
+    test_conv_igemm_vs_torch(case)
+
+
+def test_conv_geometry_limits_are_rejected():
+    """Padded convolutions take KH, KW <= 15 (include/hands_hip.h); beyond that the entry point refuses."""
+    from hands_amd._lib import ConvDesc, ptr
+    import ctypes as C
+    L = _lib.lib()
+    x = torch.zeros(1, 20, 20, 16, device=DEV)
+    w = torch.zeros(128, 16 * 16 * 16, device=DEV)
+    b = torch.zeros(128, device=DEV)
+    out = torch.zeros(1, 7, 7, 4, device=DEV)
+    d = ConvDesc(1, 20, 20, 16, 7, 7, 4, 16, 16, 1, 1, 16, 4, 0, 16 * 16 * 16, 0)
+    assert L.hands_conv2d_nhwc_f32(C.byref(d), ptr(x), ptr(w), ptr(b), None, ptr(out), _stream()) != 0
+    d = ConvDesc(1, 20, 20, 16, 8, 8, 4, 15, 15, 1, 1, 16, 4, 0, 15 * 15 * 16, 0)
+    w = torch.zeros(128, 15 * 15 * 16, device=DEV)
+    out = torch.zeros(1, 8, 8, 4, device=DEV)
+    assert L.hands_conv2d_nhwc_f32(C.byref(d), ptr(x), ptr(w), ptr(b), None, ptr(out), _stream()) == 0
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_conv_igemm_input_larger_than_2gib(k):
+    """Offsets are relative to the first image a wave stages, so a 2.6 GB input (absolute byte offsets past 2^31)
+    is fine: the last images of the batch are checked against torch."""
+    L = _lib.lib()
+    B, Cin, H, Cout = 800, 256, 56, 64
+    g = torch.Generator().manual_seed(k)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    pc = pack_conv(w, bias, 1, k // 2, DEV)
+    x = torch.randn(B, H, H, Cin, device=DEV)
+    assert x.numel() * 4 > 2 ** 31
+    out = torch.full((B, H, H, Cout), float("nan"), device=DEV)
+    DEFAULT_ENGINE.conv(L, pc, x, B, H, H, out, True, _stream())
+    torch.cuda.synchronize()
+    for b0 in (0, 417, B - 2):
+        ref = F.relu(F.conv2d(x[b0:b0 + 2].permute(0, 3, 1, 2).double().cpu(), w.double(), bias.double(), padding=k // 2))
+        got = out[b0:b0 + 2].permute(0, 3, 1, 2).double().cpu()
+        assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    del x, out
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] * c[2] * c[3] <= 3000])
 def test_conv_igemm_latency_mode_split_k(case):
     """Caller-chosen split-K on convolutions (small-batch serving mode): same result as the unsplit
