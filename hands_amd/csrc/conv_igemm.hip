@@ -8,9 +8,9 @@
 // Block tile = (64*WAVES_M pixels) x (64*WAVES_N channels), 4 waves, each wave a 64x64 tile made of
 // 2x2 MFMA 32x32 blocks (64 accumulator registers).  K is walked in steps of 16 floats (64 B per
 // row); tiles are staged global -> registers -> LDS with a two-deep LDS ring, the global loads of
-// step t+1 in flight under the 32 MFMAs (2048 matrix-pipe cycles) of step t.  LDS rows are padded
-// to 20 floats so that both the 16-byte staging writes and the ds_read_b128 fragment reads are
-// bank-conflict free.  Within a 16-wide k-step the k index is permuted (lane half h reads k =
+// step t+1 in flight under the 32 MFMAs (2048 matrix-pipe cycles) of step t.  LDS rows are one
+// k-step (16 floats, unpadded) with the four 16-byte chunks of row r XOR-swizzled by (r >> 2) & 3, which keeps
+// both the ds_write_b128 staging writes and the ds_read_b128 fragment reads bank-conflict free.  Within a 16-wide k-step the k index is permuted (lane half h reads k =
 // 8*kk + 4*h + t for MFMA t): both operands use the same permutation, so the sum is unchanged.
 //
 // Replaces: F.conv2d + eval BatchNorm2d (folded) + ReLU + residual add of
@@ -46,7 +46,10 @@ __device__ __forceinline__ float f4elem(const float4& v, int t) {
 }
 
 constexpr int BK = 16;         // floats per k-step
-constexpr int LDS_ROW = 20;    // padded LDS row (floats): 80 B = 5 x 16 B slots
+constexpr int LDS_ROW = 16;    // LDS row (floats) = one k-step, unpadded; the 16-byte chunk c of row r sits at c ^ ((r >> 2) & 3):
+                               // ds_write_b128 (8 contiguous lanes = 2 whole rows) and ds_read_b128 (its 16-lane groups of
+                               // rows {0-3,12-15,20-27} / {4-11,16-19,28-31}) are both conflict-free, and the 256 x 64 tile's
+                               // ring is 40 KB (4 workgroups per CU) instead of 50
 constexpr int LDS_ROW_B3 = 24; // bf16x3 mode: three bf16 planes of 16 k (3 x 32 B), no pad: 2-way read conflicts, but 49 KB
                                // per block = 3 blocks per CU (measured +8 % over the padded 112-B rows at 2 blocks per CU)
 
@@ -107,6 +110,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // feeding the matrix pipe: with K = 256 a tile spent 12 of its 72 us there (tools/prof_tile.py).
 // Same arithmetic as the general path: (acc + bias) + residual, then max(., 0).
 constexpr int EROW = 68;                            // 64 channels + 4 pad floats (17 slots: odd)
+constexpr int EPI_FLOATS = 4 * 32 * EROW;           // the epilogue's transposition buffers (one per wave) reuse the ring
 template <bool RELU, bool RES>
 __device__ __forceinline__ void epilogue_full(const f32x16 (&acc)[2][2], float* sE, int lane, const float* bias_p,
                                               const char* res_u, int res_ps, char* out_u, int out_ps) {
@@ -193,6 +197,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
   // ---- per-thread staging assignment: row = (tid>>2) + 64*i, 16-byte chunk = tid&3 ------------
   const int srow = tid >> 2;
   const int chunk = tid & 3;
+  const int swz_chunk = chunk ^ ((srow >> 2) & 3);     // PREC 0 ring position of this thread's 16-byte chunk (LDS_ROW)
   int x_base[A_ROWS];     // float offset of pixel (b, ho*s-pad, wo*s-pad) channel 0 (may be "negative")
   int x_hi0[A_ROWS], x_wi0[A_ROWS];
   bool x_ok[A_ROWS];
@@ -330,8 +335,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
 #define STORE_TILES(BUF)                                                                            \
   do {                                                                                              \
     if constexpr (PREC == 0) {                                                                      \
-      float* dx = sX + (BUF) * BM * ROW + srow * ROW + chunk * 4;                                   \
-      float* dw = sW + (BUF) * BN * ROW + srow * ROW + chunk * 4;                                   \
+      float* dx = sX + (BUF) * BM * ROW + srow * ROW + swz_chunk * 4;                               \
+      float* dw = sW + (BUF) * BN * ROW + srow * ROW + swz_chunk * 4;                               \
       _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i)                                            \
         *reinterpret_cast<float4*>(dx + 64 * i * ROW) = xr[i];                                      \
       _Pragma("unroll") for (int i = 0; i < W_ROWS; ++i)                                            \
@@ -382,9 +387,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
   __syncthreads();
 
   // fragment read offsets: row = lane&31, k half = lane>>5
-  const int frag = (lane & 31) * ROW + (lane >> 5) * 4;
+  // PREC 0: chunk (2 kk + half) of row r is stored at chunk ^ ((r >> 2) & 3); the kk = 1 fragment is the kk = 0 address ^ 32 B
+  const int frag = PREC ? (lane & 31) * ROW + (lane >> 5) * 4
+                        : (lane & 31) * ROW + (((lane >> 5) ^ ((lane >> 2) & 3)) * 4);
   const float* fw = sW + (wn * 64) * ROW + frag;
   const float* fx = sX + (wm * 64) * ROW + frag;
+  const float* fw1 = sW + (wn * 64) * ROW + (frag ^ 8);
+  const float* fx1 = sX + (wm * 64) * ROW + (frag ^ 8);
 
 #define COMPUTE_STEP(BUF)                                                                           \
   do {                                                                                              \
@@ -392,8 +401,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
       float4 wf[2][2], xf[2][2]; /* [32-row block][kk] */                                           \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                            \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                             \
-          wf[i][kk] = *reinterpret_cast<const float4*>(fw + (BUF) * BN * ROW + i * 32 * ROW + kk * 8); \
-          xf[i][kk] = *reinterpret_cast<const float4*>(fx + (BUF) * BM * ROW + i * 32 * ROW + kk * 8); \
+          wf[i][kk] = *reinterpret_cast<const float4*>((kk ? fw1 : fw) + (BUF) * BN * ROW + i * 32 * ROW); \
+          xf[i][kk] = *reinterpret_cast<const float4*>((kk ? fx1 : fx) + (BUF) * BM * ROW + i * 32 * ROW); \
         }                                                                                           \
       }                                                                                             \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                            \
@@ -518,7 +527,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
 
 template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0>
 __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * (64 * WAVES_M + 64 * WAVES_N) * (PREC ? LDS_ROW_B3 : LDS_ROW)];
+  constexpr int RING = 2 * (64 * WAVES_M + 64 * WAVES_N) * (PREC ? LDS_ROW_B3 : LDS_ROW);
+  __shared__ __attribute__((aligned(16))) float lds[RING > EPI_FLOATS ? RING : EPI_FLOATS];
   const int ntiles = a.nblk_m * a.nblk_n;
   const int split = a.ksplit > 1 ? blockIdx.x / ntiles : 0;
   const int tile = xcd_remap(a.ksplit > 1 ? blockIdx.x - split * ntiles : blockIdx.x, ntiles);
@@ -549,7 +559,8 @@ struct SkArgs {
 
 template <int WAVES_M, int WAVES_N, int MODE>
 __global__ void __launch_bounds__(256, 2) conv_igemm_sk_f32_kernel(ConvArgs a, SkArgs sk) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * (64 * WAVES_M + 64 * WAVES_N) * LDS_ROW];
+  constexpr int RING = 2 * (64 * WAVES_M + 64 * WAVES_N) * LDS_ROW;
+  __shared__ __attribute__((aligned(16))) float lds[RING > EPI_FLOATS ? RING : EPI_FLOATS];
   __shared__ int s_ready;
   const int G = gridDim.x;
   const int g = xcd_remap(blockIdx.x, G);
