@@ -109,6 +109,45 @@ def test_conv_igemm_random_shapes(case):
     test_conv_igemm_vs_torch(case)
 
 
+MANY_TILE_CASES = [
+    # B, Cin, H, Cout, k, stride, pad, residual -- more output tiles than CUs (several workgroups resident per CU),
+    # every output checked: a variant whose epilogue used raw-buffer STORES passed all small cases and corrupted a
+    # few lanes of a few tiles only from 257 tiles up (found by the model-level idempotence test)
+    (48, 128, 28, 128, 3, 1, 1, False),
+    (64, 128, 56, 128, 3, 2, 1, False),
+    (64, 64, 28, 64, 3, 1, 1, False),
+    (64, 128, 28, 128, 3, 1, 1, True),
+    (64, 256, 56, 128, 1, 1, 0, False),
+    (40, 256, 14, 1024, 1, 1, 0, True),
+]
+
+
+@pytest.mark.parametrize("case", MANY_TILE_CASES)
+def test_conv_igemm_many_tiles_every_output(case):
+    B, Cin, H, Cout, k, stride, pad, use_res = case
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(B + Cin + k)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    pc = pack_conv(w, bias, stride, pad, DEV)
+    x = torch.randn(B, H, H, Cin, device=DEV)
+    Ho = (H + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Ho, Ho, Cout, device=DEV) if use_res else None
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double().to(DEV), bias.double().to(DEV), stride=stride, padding=pad)
+    if res is not None:
+        ref = ref + res.permute(0, 3, 1, 2).double()
+    ref = F.relu(ref).permute(0, 2, 3, 1)
+    outs = []
+    for fill in (float("nan"), 7.0):          # twice: the result may not depend on what the output buffer held
+        out = torch.full((B, Ho, Ho, Cout), fill, device=DEV)
+        DEFAULT_ENGINE.conv(L, pc, x, B, H, H, out, True, _stream(), res=res)
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0].double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
 ADDRESSING_CASES = [
     # the k-loop addresses a tile's inputs with 32-bit byte offsets from the first image a wave touches and masks
     # taps with one validity word per output pixel: tiles spanning many tiny images, 1x1 maps with padding, a 1x1
