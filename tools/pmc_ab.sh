@@ -1,8 +1,8 @@
+# usage: bash tools/pmc_ab.sh "<shape>" <variant> [<variant> ...]   FETCH_SIZE of one conv shape under several library builds
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmcab; mkdir -p $O
-export HANDS_BENCH_SHAPES="96,1280,16,1280,1,1,0,0"
-export HANDS_STREAMK=1
-for v in old62 lean new; do
+export HANDS_BENCH_SHAPES="$1"; shift
+for v in "$@"; do
   cd /tmp
   HANDS_HIP_LIB=$R/build_ab/$v.so rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/$v -o p -- python3 $R/tools/bench_conv.py 3 > /dev/null 2> $O/$v.err
   cd $R
