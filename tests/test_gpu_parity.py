@@ -119,6 +119,9 @@ MANY_TILE_CASES = [
     (64, 128, 28, 128, 3, 1, 1, True),
     (64, 256, 56, 128, 1, 1, 0, False),
     (40, 256, 14, 1024, 1, 1, 0, True),
+    (48, 128, 28, 132, 3, 1, 1, True),      # channel tail: the general epilogue on every second tile
+    (47, 64, 27, 192, 3, 1, 1, False),      # odd map, pixel tail
+    (300, 1024, 7, 260, 1, 1, 0, True),     # many images per tile, channel tail
 ]
 
 
