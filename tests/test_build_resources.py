@@ -26,3 +26,28 @@ def test_hot_kernels_do_not_spill(tmp_path, src):
     assert names and len(names) == len(scratch) == len(spills)
     bad = [(n, s, v) for n, s, v in zip(names, scratch, spills) if s or v]
     assert not bad, bad
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_fp32_conv_kernels_keep_four_workgroups_per_cu(tmp_path):
+    """Every exact-fp32 instantiation of the plain convolution kernel must fit 4 workgroups of 4 waves on a CU:
+    <= 128 VGPRs (512 per SIMD lane / 4 waves) and <= 40 KB of LDS (160 KB / 4).  The 256x64 tile once sat at
+    130 VGPRs / 51 KB = 3 per CU."""
+    p = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{ROOT}/hands_amd/csrc",
+                        "-fno-fast-math", "-ffp-contract=off", "-Rpass-analysis=kernel-resource-usage", "-c",
+                        os.path.join(ROOT, "hands_amd", "csrc", "conv_igemm.hip"), "-o", str(tmp_path / "o.o")],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    blocks = re.split(r"Function Name: ", p.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        m = re.search(r"conv_igemm_f32_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)E", name)
+        if not m or m.group(4) != "0":          # plain kernel, PREC 0 (exact fp32) only
+            continue
+        vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
+        agprs = int(re.search(r"AGPRs: (\d+)", b).group(1))
+        lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1))
+        assert vgprs + agprs <= 128 and lds <= 40960, (name, vgprs, agprs, lds)
+        seen += 1
+    assert seen == 6
