@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Build timestamp-instrumented copies of the hot kernels into build_ab/ (dev tool; the shipped library is never
+instrumented).  The copies are made by textual patches of the CURRENT sources, so a patch that no longer applies fails
+loudly here instead of silently measuring something else.
+
+  python tools/instrument.py tile    -> build_ab/prof_tile.so    conv_igemm: per workgroup s_memrealtime at entry, after the
+                                         tile setup, after the first barrier, after the k-loop, at exit  (tools/prof_tile.py)
+  python tools/instrument.py clock   -> build_ab/prof_clock.so   conv_igemm: s_memrealtime + s_memtime at entry / exit of every
+                                         workgroup (tools/prof_clock.py)
+  python tools/instrument.py ring    -> build_ab/prof_ring.so    conv_igemm: the middle workgroup of every plain launch stamps
+                                         both clocks into a ring (tools/prof_ring.py)
+  python tools/instrument.py stem    -> build_ab/prof_stem.so    stem_pool_planar_kernel: entry / after the patch fill / after
+                                         the GEMM / exit (tools/stem_prof.py)
+Then e.g.:  HANDS_HIP_LIB=build_ab/prof_tile.so python tools/prof_tile.py 256,256,32,256,1,1,0,0
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONV = os.path.join(ROOT, "hands_amd", "csrc", "conv_igemm.hip")
+STEM = os.path.join(ROOT, "hands_amd", "csrc", "stem_pool.hip")
+
+
+def sub(s, old, new, what):
+    assert s.count(old) == 1, f"patch anchor not found exactly once ({what}): {old[:60]!r}"
+    return s.replace(old, new, 1)
+
+
+def stamp(array, slot, cond="prof"):
+    return (f"__builtin_amdgcn_sched_barrier(0); if ({cond}) {array}[blockIdx.x * 8 + {slot}] = "
+            f"__builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0);")
+
+
+def conv_tile_timeline():
+    s = open(CONV).read()
+    s = sub(s, "namespace {\n\ntypedef float f32x16", """__device__ unsigned long long g_prof[16384 * 8];
+__device__ unsigned long long g_steps[64 * 256];
+extern "C" int hands_debug_prof(void* dst, void* dst2) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16384 * 8);
+  hipMemcpyFromSymbol(dst2, HIP_SYMBOL(g_steps), sizeof(unsigned long long) * 64 * 256);
+  return 0;
+}
+namespace {
+
+typedef float f32x16""", "globals")
+    s = sub(s, "  LOAD_TILES(kt0);\n  STORE_TILES(0);\n  __syncthreads();\n",
+            "  const bool prof = threadIdx.x == 0 && blockIdx.x < 16384;\n  " + stamp("g_prof", 1) +
+            "\n  LOAD_TILES(kt0);\n  STORE_TILES(0);\n  __syncthreads();\n  " + stamp("g_prof", 2) + "\n", "prologue")
+    s = sub(s, "  COMPUTE_STEP((kt1 - 1 - kt0) & 1);\n#undef COMPUTE_STEP\n",
+            "  COMPUTE_STEP((kt1 - 1 - kt0) & 1);\n#undef COMPUTE_STEP\n  " + stamp("g_prof", 3) + "\n", "loop end")
+    s = sub(s, "    return;\n  }\n  const float4 bv = part", "    " + stamp("g_prof", 4) + "\n    return;\n  }\n  const float4 bv = part",
+            "lean epilogue end")
+    s = sub(s, "#undef LOAD_TILES\n#undef STORE_TILES\n}", "  " + stamp("g_prof", 4) + "\n#undef LOAD_TILES\n#undef STORE_TILES\n}",
+            "general epilogue end")
+    s = sub(s, "  const int ntiles = a.nblk_m * a.nblk_n;\n  const int split = a.ksplit > 1 ? blockIdx.x / ntiles : 0;\n",
+            "  if (threadIdx.x == 0 && blockIdx.x < 16384) g_prof[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();\n"
+            "  const int ntiles = a.nblk_m * a.nblk_n;\n  const int split = a.ksplit > 1 ? blockIdx.x / ntiles : 0;\n", "kernel entry")
+    return s, "conv_igemm.hip"
+
+
+def conv_clock():
+    s = open(CONV).read()
+    s = sub(s, "namespace {\n\ntypedef float f32x16", """__device__ unsigned long long g_prof[32768 * 4];
+extern "C" int hands_debug_prof(void* dst, void* dst2) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 32768 * 4);
+  return 0;
+}
+namespace {
+
+typedef float f32x16""", "globals")
+    s = sub(s, "  const int ntiles = a.nblk_m * a.nblk_n;\n  const int split = a.ksplit > 1 ? blockIdx.x / ntiles : 0;\n",
+            "  if (threadIdx.x == 0 && blockIdx.x < 32768) { g_prof[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime(); "
+            "g_prof[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime(); }\n"
+            "  const int ntiles = a.nblk_m * a.nblk_n;\n  const int split = a.ksplit > 1 ? blockIdx.x / ntiles : 0;\n", "kernel entry")
+    s = sub(s, "  conv_tile<WAVES_M, WAVES_N, MODE, PREC>(a, lds, tile, split, kt0, kt1, nullptr, nullptr);\n}",
+            "  conv_tile<WAVES_M, WAVES_N, MODE, PREC>(a, lds, tile, split, kt0, kt1, nullptr, nullptr);\n"
+            "  if (threadIdx.x == 0 && blockIdx.x < 32768) { g_prof[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime(); "
+            "g_prof[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime(); }\n}", "kernel exit")
+    return s, "conv_igemm.hip"
+
+
+def conv_ring():
+    s = open(CONV).read()
+    s = sub(s, "namespace {\n\ntypedef float f32x16", """__device__ unsigned long long g_ring[8192 * 4];
+__device__ unsigned int g_n;
+extern "C" int hands_debug_ring(void* dst, unsigned int* n, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ring), sizeof(unsigned long long) * 8192 * 4);
+  hipMemcpyFromSymbol(n, HIP_SYMBOL(g_n), sizeof(unsigned int));
+  if (reset) { unsigned int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_n), &z, sizeof(z)); }
+  return 0;
+}
+namespace {
+
+typedef float f32x16""", "globals")
+    s = sub(s, "  const int ntiles = a.nblk_m * a.nblk_n;\n  const int split = a.ksplit > 1 ? blockIdx.x / ntiles : 0;\n",
+            "  unsigned long long rt0 = 0, mt0 = 0;\n  const bool stamp = threadIdx.x == 0 && blockIdx.x == gridDim.x / 2;\n"
+            "  if (stamp) { rt0 = __builtin_amdgcn_s_memrealtime(); mt0 = __builtin_amdgcn_s_memtime(); }\n"
+            "  const int ntiles = a.nblk_m * a.nblk_n;\n  const int split = a.ksplit > 1 ? blockIdx.x / ntiles : 0;\n", "kernel entry")
+    s = sub(s, "  conv_tile<WAVES_M, WAVES_N, MODE, PREC>(a, lds, tile, split, kt0, kt1, nullptr, nullptr);\n}",
+            "  conv_tile<WAVES_M, WAVES_N, MODE, PREC>(a, lds, tile, split, kt0, kt1, nullptr, nullptr);\n"
+            "  if (stamp) {\n    const unsigned i = atomicAdd(&g_n, 1u) & 8191u;\n    g_ring[i * 4 + 0] = rt0; g_ring[i * 4 + 1] = mt0;\n"
+            "    g_ring[i * 4 + 2] = __builtin_amdgcn_s_memrealtime(); g_ring[i * 4 + 3] = __builtin_amdgcn_s_memtime();\n  }\n}",
+            "kernel exit")
+    return s, "conv_igemm.hip"
+
+
+def stem_phases():
+    s = open(STEM).read()
+    s = sub(s, "namespace {\n", "__device__ unsigned long long g_sprof[8192 * 4];\n"
+            "extern \"C\" int hands_debug_sprof(void* dst) { hipDeviceSynchronize(); hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_sprof), "
+            "sizeof(unsigned long long) * 8192 * 4); return 0; }\nnamespace {\n", "globals")
+    i = s.index("stem_pool_planar_kernel(")
+    head, body = s[:i], s[i:]
+    st = ("__builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 8192) g_sprof[blockIdx.x * 4 + %d] = "
+          "__builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0);")
+    body = sub(body, "  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n",
+               "  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n  " + st % 0 + "\n", "entry")
+    body = sub(body, "  // ---- 256 x 64 x 160 GEMM, 64 rows per wave", "  " + st % 1 + "\n  // ---- 256 x 64 x 160 GEMM, 64 rows per wave", "gemm")
+    body = sub(body, "  // ---- pool through LDS, 16 channels per round (same max order",
+               "  " + st % 2 + "\n  // ---- pool through LDS, 16 channels per round (same max order", "pool")
+    body = sub(body, "\n}\n\n}  // namespace", "\n  " + st % 3 + "\n}\n\n}  // namespace", "exit")
+    return head + body, "stem_pool.hip"
+
+
+KINDS = {"tile": (conv_tile_timeline, "prof_tile"), "clock": (conv_clock, "prof_clock"), "ring": (conv_ring, "prof_ring"),
+         "stem": (stem_phases, "prof_stem")}
+
+if __name__ == "__main__":
+    kinds = sys.argv[1:] or list(KINDS)
+    for k in kinds:
+        fn, name = KINDS[k]
+        src, replaces = fn()
+        with tempfile.NamedTemporaryFile("w", suffix=".hip", delete=False) as f:
+            f.write(src)
+        subprocess.check_call([os.path.join(ROOT, "tools", "build_variant.sh"), name, "-", f.name, replaces])
+        os.unlink(f.name)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Shader clock over the life of ONE conv_igemm launch (dev tool): every workgroup stamps s_memrealtime (100 MHz) and
-s_memtime (shader clock) at entry and exit; needs a library built from an instrumented copy of conv_igemm.hip.
-usage: HANDS_HIP_LIB=build_ab/clk.so python tools/prof_clock.py B,Cin,H,Cout,k,stride,pad,res [...]"""
+s_memtime (shader clock) at entry and exit; needs python tools/instrument.py clock.
+usage: HANDS_HIP_LIB=build_ab/prof_clock.so python tools/prof_clock.py B,Cin,H,Cout,k,stride,pad,res [...]"""
 import ctypes as C
 import os
 import sys

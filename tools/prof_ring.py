@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Shader clock seen by the conv_igemm launches of whole forwards (dev tool; library built from a copy of conv_igemm.hip
 in which the middle workgroup of every plain launch stamps s_memrealtime / s_memtime at entry and exit into a ring).
-usage: HANDS_HIP_LIB=build_ab/ring.so python tools/prof_ring.py [serial|overlap] [bz]"""
+usage: HANDS_HIP_LIB=build_ab/prof_ring.so python tools/prof_ring.py [serial|overlap] [bz]"""
 import ctypes as C
 import os
 import sys

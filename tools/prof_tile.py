@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-workgroup timeline of ONE conv_igemm launch (dev tool; needs a library built from a timestamp-instrumented
-copy of conv_igemm.hip: the variant exports hands_debug_prof, see profiles/README.md "tile timeline").
-usage: HANDS_HIP_LIB=build_ab/prof.so python tools/prof_tile.py B,Cin,H,Cout,k,stride,pad,res [...]"""
+copy of conv_igemm.hip: python tools/instrument.py tile).
+usage: HANDS_HIP_LIB=build_ab/prof_tile.so python tools/prof_tile.py B,Cin,H,Cout,k,stride,pad,res [...]"""
 import ctypes as C
 import os
 import sys

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Phase durations of stem_pool_planar_kernel inside real hands_light forwards (dev tool; python tools/instrument.py stem).
+usage: HANDS_HIP_LIB=build_ab/prof_stem.so python tools/stem_prof.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 os.environ.setdefault("HANDS_SYNTHETIC_MANO", "1")
