@@ -571,10 +571,14 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sk_f32_kernel(ConvArgs a, S
   const int ta = (int)(u0 / nk), ka = (int)(u0 - (long long)ta * nk);
   const int tb = (int)(u1 / nk), kb = (int)(u1 - (long long)tb * nk);
 
+  // G > tiles (1-2 tiles per CU, two workgroups per CU): a range may lie INSIDE one tile -- k-steps [ka, kb) of tile
+  // ta, continuing workgroup g-1's chain AND handing its own accumulators on.  The chain of a tile is then up to
+  // three workgroups long; every link waits (bounded) for the previous one and otherwise recomputes from k = 0
+  const bool inside = ta == tb;                       // kb > ka > = 0 then: u1 > u0
   const int first_full = ka > 0 ? ta + 1 : ta;
-  const int nfull = tb - first_full;
-  const int head = kb > 0 ? 1 : 0;
-  const int nseg = head + nfull + (ka > 0 ? 1 : 0);
+  const int nfull = inside ? 0 : tb - first_full;
+  const int head = (!inside && kb > 0) ? 1 : 0;
+  const int nseg = inside ? 1 : head + nfull + (ka > 0 ? 1 : 0);
   for (int sgi = 0; sgi < nseg; ++sgi) {              // one call site: the tile code is instantiated once
     int tile, k0 = 0, k1 = nk;
     const float* ain = nullptr;
@@ -584,7 +588,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sk_f32_kernel(ConvArgs a, S
       aout = sk.slots + (size_t)g * SK_SLOT_FLOATS;
     } else if (sgi - head < nfull) {                  // 2. full tiles
       tile = first_full + (sgi - head);
-    } else {                                          // 3. tail part of the tile the range starts in
+    } else if (inside && ka == 0) {                   // 1'. the range is the first part of one tile
+      tile = ta; k1 = kb;
+      aout = sk.slots + (size_t)g * SK_SLOT_FLOATS;
+    } else {                                          // 3. tail part of the tile the range starts in (or 3'. a middle part)
       if (threadIdx.x == 0) {
         int ok = 0;
         for (int spin = 0; spin < 4096 && !ok; ++spin) {
@@ -597,6 +604,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sk_f32_kernel(ConvArgs a, S
       __syncthreads();
       tile = ta;
       if (s_ready != 0) { k0 = ka; ain = sk.slots + (size_t)(g - 1) * SK_SLOT_FLOATS; }
+      if (inside) { k1 = kb; aout = sk.slots + (size_t)g * SK_SLOT_FLOATS; }
     }
     __syncthreads();                                  // the staging LDS of the previous segment is free
     conv_tile<WAVES_M, WAVES_N, MODE>(a, lds, tile, 0, k0, k1, ain, aout);
@@ -658,6 +666,11 @@ int sk_blocks_per_cu() {
 int streamk_grid(long long ntiles, int nk, int cus, int max_per_cu) {
   // measured (profiles/README.md): 784- and 1568-tile launches gain 8-22 %; short-K pointwise layers with thousands
   // of tiles lose (the hand-off is a fixed 64 KB write + read per workgroup)
+  if (ntiles > cus + cus / 8 && ntiles < 2LL * cus && nk >= 128 && max_per_cu >= 2) {
+    // 1.1-2 tiles per CU with a long K (layer4's 3x3 at 256 images, feature_conv: 392-400 tiles, 288-576 k-steps): the
+    // plain launch runs two workgroups on some CUs and one on the others; 2 per CU with equal shares is 0.77 of that
+    return 2 * cus;
+  }
   if (nk < 16 || ntiles < 2LL * cus || ntiles > 8LL * cus) return 0;
   const double per_cu = (double)ntiles / cus;
   const long long rounds = (ntiles + cus - 1) / cus;

@@ -244,6 +244,9 @@ SK_CASES = [
     (150, 256, 14, 1024, 1, 1, 0, True),     # expand + residual + relu
     (37, 128, 28, 128, 3, 2, 1, False),      # stride 2, ragged M
     (300, 64, 14, 64, 3, 1, 1, False),       # narrow 256 x 64 tile instantiation
+    (256, 512, 7, 512, 3, 1, 1, False),      # 392 tiles (1.5 per CU), 288 k-steps: 512 workgroups, ranges INSIDE a tile
+    (512, 1024, 7, 512, 3, 1, 0, False),     # feature_conv: 400 tiles, 576 k-steps
+    (256, 2048, 7, 512, 1, 1, 0, True),      # pointwise in the same regime, with residual
 ]
 
 
@@ -275,6 +278,8 @@ def test_stream_k_is_bit_identical_to_the_plain_launch(case):
         assert G > 0 and G % 256 == 0, G
     if case is SK_CASES[1]:
         assert G == 0
+    if case is SK_CASES[6]:
+        assert G == 512, G
 
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 256, 56, 1), (3, 128, 256, 512, 28, 2), (1, 512, 1024, 2048, 14, 2), (2, 16, 32, 12, 9, 2)])
