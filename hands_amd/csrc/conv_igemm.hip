@@ -614,7 +614,8 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sk_f32_kernel(ConvArgs a, S
       if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(sk.flags + g, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (a negative epoch is the test hook for the fallback: nobody publishes, every consumer times out and recomputes)
+        if (sk.epoch > 0) __hip_atomic_store(sk.flags + g, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }

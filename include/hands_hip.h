@@ -107,7 +107,9 @@ int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const float* in, co
  * or very many tiles, < 5 % to gain) -- the call is then identical to hands_conv2d_nhwc_f32.
  * workspace: hands_conv2d_streamk_workspace_bytes() bytes of device memory, ZEROED once by the caller, private to
  * one stream at a time; epoch: any nonzero value different from the one passed with the previous call on the
- * same workspace (a per-workspace counter). */
+ * same workspace (a per-workspace counter), POSITIVE in production.  A negative epoch is a test hook: no workgroup
+ * publishes its hand-off, so every consumer takes the bounded-wait fallback and recomputes the missing k-steps
+ * itself (slow, same bits). */
 long long hands_conv2d_streamk_workspace_bytes(void);
 int hands_conv2d_streamk_grid(const hands_conv_desc* d);
 int hands_conv2d_nhwc_streamk_f32(const hands_conv_desc* d, const float* in, const float* w_packed,

@@ -282,6 +282,37 @@ def test_stream_k_is_bit_identical_to_the_plain_launch(case):
         assert G == 512, G
 
 
+@pytest.mark.parametrize("case", [SK_CASES[0], SK_CASES[6], SK_CASES[8]])
+def test_stream_k_fallback_recomputes_the_same_bits(case):
+    """No workgroup publishes its accumulator hand-off (negative epoch = the test hook): every consumer -- tail parts
+    and, with 512 workgroups on 392 tiles, the parts in the MIDDLE of a tile -- runs into its bounded wait and
+    recomputes the missing k-steps itself.  Same bits as the plain launch."""
+    import ctypes as C
+    from hands_amd._lib import ptr
+    B, Cin, H, Cout, k, stride, pad, use_res = case
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(B, H, H, Cin, generator=g).to(DEV)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    pc = pack_conv(w, torch.randn(Cout, generator=g), stride, pad, DEV)
+    Ho = (H + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Ho, Ho, Cout, generator=g).to(DEV) if use_res else None
+    plain = ConvEngine()
+    plain.stream_k = False
+    ref = torch.full((B, Ho, Ho, pc.Cout), float("nan"), device=DEV)
+    plain.conv(L, pc, x, B, H, H, ref, True, _stream(), res=res)
+    d = _lib.ConvDesc(B, H, H, pc.Cin, Ho, Ho, pc.Cout, k, k, stride, pad, pc.Cin, pc.Cout, pc.Cout if use_res else 0, pc.Kpad, 1)
+    assert L.hands_conv2d_streamk_grid(C.byref(d)) > 0
+    ws = torch.zeros(L.hands_conv2d_streamk_workspace_bytes() // 4, dtype=torch.int32, device=DEV)
+    got = torch.full((B, Ho, Ho, pc.Cout), float("nan"), device=DEV)
+    torch.cuda.synchronize()
+    rc = L.hands_conv2d_nhwc_streamk_f32(C.byref(d), ptr(x), ptr(pc.w), ptr(pc.bias), ptr(res) if use_res else None, ptr(got),
+                                         ptr(ws), ws.numel() * 4, -7, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize("case", [(2, 64, 64, 256, 56, 1), (3, 128, 256, 512, 28, 2), (1, 512, 1024, 2048, 14, 2), (2, 16, 32, 12, 9, 2)])
 def test_conv1x1_dual_vs_torch(case):
     """relu(conv1x1(x) + conv1x1_stride(x2) + bias): conv3 + downsample of a bottleneck as one GEMM."""
