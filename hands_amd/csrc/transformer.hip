@@ -156,10 +156,23 @@ __global__ void __launch_bounds__(64 * TB) attention_kernel(const float* __restr
   const float* base = qkv + (long long)b * T * 3 * C + h * D;
 
   // K tile -> LDS (coalesced 16-B loads along d)
-  for (int i = tid; i < T * (D / 4); i += NT) {
-    const int t = i / (D / 4), dq = i - t * (D / 4);
-    const float4 v = *reinterpret_cast<const float4*>(base + (long long)t * 3 * C + C + dq * 4);
-    *reinterpret_cast<float4*>(lds + t * KR + dq * 4) = v;
+  // (all loads of a thread in flight before its first LDS store: T * D / 4 is a multiple of the block size)
+  constexpr int FILL = T * (D / 4) / NT;
+  static_assert(T * (D / 4) % NT == 0, "fill loops assume whole iterations");
+  {
+    float4 kv[FILL];
+#pragma unroll
+    for (int it = 0; it < FILL; ++it) {
+      const int i = tid + it * NT;
+      const int t = i / (D / 4), dq = i - t * (D / 4);
+      kv[it] = *reinterpret_cast<const float4*>(base + (long long)t * 3 * C + C + dq * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < FILL; ++it) {
+      const int i = tid + it * NT;
+      const int t = i / (D / 4), dq = i - t * (D / 4);
+      *reinterpret_cast<float4*>(lds + t * KR + dq * 4) = kv[it];
+    }
   }
   // this wave's Q fragments (pre-scaled: vit.py:118 scales q before the matmul)
   float4 qf[D / 8];
