@@ -34,6 +34,19 @@ __global__ void __launch_bounds__(256) write_kernel(float4* __restrict__ out, si
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = make_float4(1.f, 2.f, 3.f, 4.f);
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// non-temporal variants (nt bit on the instruction): do streaming stores / loads get a better rate past the L2?
+__global__ void __launch_bounds__(256) copy_nt_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, size_t n, int mode) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = (mode & 1) ? __builtin_nontemporal_load(&in[i]) : in[i];
+    if (mode & 2) __builtin_nontemporal_store(v, &out[i]); else out[i] = v;
+  }
+}
+__global__ void __launch_bounds__(256) write_nt_kernel(f32x4* __restrict__ out, size_t n) {
+  const f32x4 v = {1.f, 2.f, 3.f, 4.f};
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) __builtin_nontemporal_store(v, &out[i]);
+}
+
 template <class F> float time_ms(F f, int reps) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int i = 0; i < 3; ++i) f();
@@ -62,6 +75,15 @@ int main() {
     const float mw = time_ms([&] { hipLaunchKernelGGL(write_kernel, dim3(grid), dim3(256), 0, 0, y, n); }, 5);
     printf("HBM stream, grid %5d: copy %.2f TB/s (read+write), read-only %.2f TB/s, write-only %.2f TB/s (datasheet 8.0)\n",
            grid, 2.0 * bytes / mc / 1e9, (double)bytes / mr / 1e9, (double)bytes / mw / 1e9);
+  }
+  for (int mode = 0; mode < 4; ++mode) {
+    const float mc = time_ms([&] { hipLaunchKernelGGL(copy_nt_kernel, dim3(8192), dim3(256), 0, 0, (const f32x4*)x, (f32x4*)y, n, mode); }, 5);
+    printf("copy, grid 8192, %s loads, %s stores: %.2f TB/s (read+write)\n", (mode & 1) ? "nt" : "plain", (mode & 2) ? "nt" : "plain",
+           2.0 * bytes / mc / 1e9);
+  }
+  {
+    const float mw = time_ms([&] { hipLaunchKernelGGL(write_nt_kernel, dim3(8192), dim3(256), 0, 0, (f32x4*)y, n); }, 5);
+    printf("write-only, nt stores: %.2f TB/s\n", (double)bytes / mw / 1e9);
   }
   return 0;
 }
