@@ -111,7 +111,7 @@ SIGNATURES = {
     "hands_pack_mano_f32": [_P] * 10,
 }
 EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string", "hands_conv2d_workspace_floats",
-                 "hands_conv2d_streamk_workspace_bytes")
+                 "hands_conv2d_streamk_workspace_bytes", "hands_stream_is_capturing")
 
 _lib = None
 
@@ -135,6 +135,8 @@ def lib():
     h.hands_conv2d_streamk_workspace_bytes.restype = C.c_longlong
     h.hands_conv2d_streamk_workspace_bytes.argtypes = []
     h.hands_abi_version.restype = C.c_int
+    h.hands_stream_is_capturing.restype = C.c_int
+    h.hands_stream_is_capturing.argtypes = [C.c_void_p]
     h.hands_error_string.restype = C.c_char_p
     h.hands_error_string.argtypes = [C.c_int]
     _lib = h

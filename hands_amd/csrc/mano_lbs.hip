@@ -589,6 +589,13 @@ int hands_mano_skin_f32(const hands_mano_consts* c, const float* v_posed, int ld
 
 int hands_abi_version(void) { return HANDS_ABI_VERSION; }
 
+int hands_stream_is_capturing(hands_stream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  hipError_t e = hipStreamIsCapturing((hipStream_t)stream, &st);
+  if (e != hipSuccess) return -(int)e;
+  return st == hipStreamCaptureStatusNone ? 0 : 1;
+}
+
 const char* hands_error_string(int code) {
   if (code == 0) return "ok";
   if (code == HANDS_EINVAL) return "hands: invalid argument / descriptor";

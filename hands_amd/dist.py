@@ -20,6 +20,7 @@ import torch.distributed as dist
 from .xdict import stream_xdict, xdict
 
 _gather_streams = {}   # device -> side stream the asynchronous gather runs on
+_single_buffer_gather = {}   # (backend, device type) -> False once all_gather_into_tensor proved unavailable
 
 
 def shard_range(bz: int, rank: int, world: int):
@@ -105,10 +106,20 @@ def gather_predictions(out: dict, group=None, global_bz: int | None = None) -> x
     rows = None if global_bz is None else max_shard(global_bz, world)
     flat, layout = pack_predictions(out, rows)
     full = torch.empty((world * flat.shape[0], flat.shape[1]), dtype=flat.dtype, device=flat.device)
-    try:
-        dist.all_gather_into_tensor(full, flat, group=group)
-    except NotImplementedError:        # a backend without the single-buffer form: same bytes, list form
-        parts = [torch.empty_like(flat) for _ in range(world)]
+    if _single_buffer_gather.get((dist.get_backend(group), flat.device.type), True):
+        try:
+            dist.all_gather_into_tensor(full, flat, group=group)
+        except (NotImplementedError, RuntimeError) as e:
+            # a backend / version without the single-buffer form (older gloo: "no support for _allgather_base");
+            # every rank takes this branch together (same backend), the choice is cached per backend and device type.
+            # Anything else (a real collective failure) is re-raised.
+            msg = str(e).lower()
+            if not isinstance(e, NotImplementedError) and not any(
+                    t in msg for t in ("allgather_base", "all_gather_into_tensor", "not support", "not implemented")):
+                raise
+            _single_buffer_gather[(dist.get_backend(group), flat.device.type)] = False
+    if not _single_buffer_gather.get((dist.get_backend(group), flat.device.type), True):
+        parts = [torch.empty_like(flat) for _ in range(world)]      # same bytes, list form
         dist.all_gather(parts, flat, group=group)
         full = torch.cat(parts, 0)
     if global_bz is not None:
@@ -133,8 +144,10 @@ def data_parallel_forward(model, inputs, meta_info, group=None, gather_on_host=F
     li, lm = shard_batch(inputs, meta_info, rank, world)
     out = model(li, lm)
     lo, hi = shard_range(bz, rank, world)
-    if world > 1 and hi - lo != next(iter(out.values())).shape[0]:      # empty shard: drop the stand-in row
-        out = {k: v[: hi - lo] for k, v in out.items()}
+    if world > 1 and hi == lo:      # empty shard (decided WITHOUT touching `out`): drop the stand-in row
+        out = {k: v[:0] for k, v in out.items()}
+    # a non-empty shard is passed on untouched: a pending stream_xdict keeps the asynchronous tail un-joined and
+    # gather_predictions packs + gathers on its side stream behind it
     if gather_on_host:
         out = {k: v.cpu() for k, v in out.items()}
     return gather_predictions(out, group, global_bz=bz if world > 1 else None)

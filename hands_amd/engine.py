@@ -37,7 +37,9 @@ class ConvEngine:
                                       # k-16 step with fp32 accumulation (HANDS_MATH_BF16X3); never the headline
         self.fuse_mano = True         # MANOHead.forward of both hands as one launch (hands_mano_heads_f32)
         self.hook = None              # callable(phase, pc, npix, stream_handle, has_res, kernel): bench.py brackets
-                                      # every MFMA launch (conv_igemm and the fused stem) with events
+                                      # every MFMA launch (conv_igemm and the fused stem) with events; `kernel` is the
+                                      # kernel the launch really runs (conv_igemm_f32_kernel / conv_igemm_sk_f32_kernel =
+                                      # stream-K / conv_igemm_splitk_f32_kernel = split-K + reduce / stem_pool_*)
         self._splitk_ws = {}          # (device, stream handle) -> workspace tensor
         self._sk_ws = {}              # (device, stream handle) -> [zeroed stream-K workspace, epoch counter]
 
@@ -47,10 +49,30 @@ class ConvEngine:
             setattr(e, k, getattr(self, k))
         return e
 
-    def _workspace(self, dev, stream, need):
+    def release_workspaces(self, dev=None):
+        """Drop the per-stream split-K / stream-K workspaces (all devices, or one).  They are keyed by the raw
+        stream handle the launch went to: a model calls this when it drops its side streams (``invalidate_packed``,
+        ``.to()``), so a later stream that happens to get a recycled handle starts from a fresh, zero-filled
+        workspace and no destroyed stream keeps 64 MB pinned."""
+        for table in (self._splitk_ws, self._sk_ws):
+            for key in [k for k in table if dev is None or k[0] == dev]:
+                del table[key]
+
+    @staticmethod
+    def _capturing(L, stream):
+        """hipGraph capture status of the stream the launch GOES TO (not of torch's current stream)."""
+        st = L.hands_stream_is_capturing(stream)
+        if st < 0:
+            raise RuntimeError(f"hands_amd: hipStreamIsCapturing failed: {L.hands_error_string(-st).decode()}")
+        return bool(st)
+
+    def _workspace(self, L, dev, stream, need):
         key = (dev, stream)
         ws = self._splitk_ws.get(key)
         if ws is None or ws.numel() < need:
+            if self._capturing(L, stream):
+                raise RuntimeError("hands_amd: a split-K workspace has to grow inside a hipGraph capture; run one eager "
+                                   "forward at this batch size first (GraphedForward does)")
             if ws is not None:
                 # a kernel on a raw side-stream handle may still read the old block, and the caching
                 # allocator only knows torch's current stream: drain before dropping it (growth is rare --
@@ -72,8 +94,6 @@ class ConvEngine:
                      (pc.Cout if res_ps is None else res_ps) if res is not None else 0,
                      pc.Kpad, int(relu) | (MATH_BF16X3 if self.math == "bf16x3" else 0))   # relu: bool or a HANDS_ACT_* code
         hook = self.hook
-        if hook is not None:
-            hook("begin", pc, B * Ho * Wo, stream, res is not None, "conv_igemm_f32_kernel")
         S = L.hands_conv2d_splitk_factor(C.byref(d)) if (splitk and self.use_splitk) else 1
         if splitk_n > 1 and self.use_splitk:
             S = splitk_n
@@ -83,14 +103,18 @@ class ConvEngine:
             bm, bn = (256, 64) if pc.Cout <= 64 else (128, 128)
             tiles = -(-(B * Ho * Wo) // bm) * -(-pc.Cout // bn)
             S = max(S, min(256 // tiles, pc.Kpad // 128, 32)) if tiles <= 128 else S
+        rp = ptr(res, res_off) if res is not None else None
+        use_sk = S <= 1 and self.math == "fp32" and ((not self.overlap) if self.stream_k == "auto" else self.stream_k) and \
+            L.hands_conv2d_streamk_grid(C.byref(d)) > 0 and not self._capturing(L, stream)
+        # (not under hipGraph capture: the zero-filled workspace of a new stream cannot be set up inside one)
+        kname = "conv_igemm_splitk_f32_kernel" if S > 1 else ("conv_igemm_sk_f32_kernel" if use_sk else "conv_igemm_f32_kernel")
+        if hook is not None:
+            hook("begin", pc, B * Ho * Wo, stream, res is not None, kname)
         if S > 1:     # latency-bound GEMM: deterministic split-K with a per-stream workspace
-            ws = self._workspace(x.device, stream, L.hands_conv2d_workspace_floats(C.byref(d), S))
-            check(L.hands_conv2d_nhwc_splitk_n_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
-                                                   ptr(res, res_off) if res is not None else None, ptr(out, out_off),
+            ws = self._workspace(L, x.device, stream, L.hands_conv2d_workspace_floats(C.byref(d), S))
+            check(L.hands_conv2d_nhwc_splitk_n_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias), rp, ptr(out, out_off),
                                                    S, ptr(ws), ws.numel(), stream), "hands_conv2d_nhwc_splitk_n_f32")
-        elif self.math == "fp32" and ((not self.overlap) if self.stream_k == "auto" else self.stream_k) and \
-                L.hands_conv2d_streamk_grid(C.byref(d)) > 0 and not torch.cuda.is_current_stream_capturing():
-            # (not under hipGraph capture: the zero-filled workspace of a new stream cannot be set up inside one)
+        elif use_sk:
             key = (x.device, stream)
             sk = self._sk_ws.get(key)
             if sk is None:
@@ -98,16 +122,14 @@ class ConvEngine:
                 sk = self._sk_ws[key] = [torch.zeros(nbytes // 4, dtype=torch.int32, device=x.device), 0]
                 torch.cuda.current_stream(x.device).synchronize()     # zero-fill done before a side stream uses it
             sk[1] = sk[1] % 0x7FFFFFF0 + 1
-            check(L.hands_conv2d_nhwc_streamk_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
-                                                  ptr(res, res_off) if res is not None else None, ptr(out, out_off),
+            check(L.hands_conv2d_nhwc_streamk_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias), rp, ptr(out, out_off),
                                                   ptr(sk[0]), sk[0].numel() * 4, sk[1], stream),
                   "hands_conv2d_nhwc_streamk_f32")
         else:
-            check(L.hands_conv2d_nhwc_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias),
-                                          ptr(res, res_off) if res is not None else None, ptr(out, out_off),
+            check(L.hands_conv2d_nhwc_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias), rp, ptr(out, out_off),
                                           stream), "hands_conv2d_nhwc_f32")
         if hook is not None:
-            hook("end", pc, B * Ho * Wo, stream, res is not None, "conv_igemm_f32_kernel")
+            hook("end", pc, B * Ho * Wo, stream, res is not None, kname)
         return Ho, Wo
 
     def conv_dual(self, L, pc, split, x, x2, B, Ho, Wo, H2, W2, out, stream, act=1, out_off=0):

@@ -209,6 +209,26 @@ class HAMER(EngineSwitches, nn.Module):
         self.chunks = 2   # the 2*bz crops run as this many jobs on separate HIP streams (1 = single stream)
         self._ws = {}
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_packed())
+        self._load_pretrained(get("pretrained", "vit"))
+
+    def _load_pretrained(self, which):
+        """model.py:33-44 with the reference's semantics: ``args.get('pretrained', 'vit')`` -- an args object
+        WITHOUT the key asks for the ViTPose backbone; a missing ``$DATA_DIR`` / file raises as ``torch.load``
+        does there; any other value (the configs use ``'none'``) keeps the initial weights.
+        ``'vit'``:   ``$DATA_DIR/hamer_training_data/vitpose_backbone.pth['state_dict']`` into ``backbone``,
+                     ``strict=False`` (the ViTPose file carries no ``kpe`` / decoder entries and may carry extra ones);
+        ``'hamer'``: ``$DATA_DIR/hamer/_DATA/hamer_ckpts/checkpoints/hamer.ckpt['state_dict']``: the keys that contain
+                     ``backbone`` / ``mano_head`` with that prefix removed, both loaded STRICTLY."""
+        if which == "vit":
+            fn = f"{os.environ['DATA_DIR']}/hamer_training_data/vitpose_backbone.pth"
+            sd = torch.load(fn, map_location="cpu", weights_only=False)["state_dict"]
+            self.backbone.load_state_dict(sd, strict=False)
+        elif which == "hamer":
+            fn = f"{os.environ['DATA_DIR']}/hamer/_DATA/hamer_ckpts/checkpoints/hamer.ckpt"
+            sd = torch.load(fn, map_location="cpu", weights_only=False)["state_dict"]
+            self.backbone.load_state_dict({k.replace("backbone.", ""): v for k, v in sd.items() if "backbone" in k})
+            self.mano_head.load_state_dict({k.replace("mano_head.", ""): v for k, v in sd.items() if "mano_head" in k})
+        self.invalidate_packed()
 
     def invalidate_packed(self):
         self._packed = None

@@ -113,6 +113,79 @@ class MANOHead(nn.Module):
         return self.mano.faces
 
 
+_MANO_OUT_SHAPES = (("vertices", (778, 3)), ("v3d.cam", (778, 3)), ("joints3d", (21, 3)), ("j3d.cam", (21, 3)),
+                    ("j2d.norm", (21, 2)), ("cam_t", (3,)))
+
+
+def _mano_out_buffers(bz, dev):
+    """The twelve output tensors of the two MANO heads as contiguous views of ONE allocation (one allocator call per
+    forward); the two vertex arrays come first in each side's 16-byte aligned block (the kernel stores them 8 bytes wide)."""
+    side_floats = (bz * 4839 + 3) // 4 * 4
+    flat = torch.empty(2 * side_floats, device=dev)
+    outs = []
+    for side in range(2):
+        o, off = {}, side * side_floats
+        for name, shp in _MANO_OUT_SHAPES:
+            n = bz
+            for d_ in shp:
+                n *= d_
+            o[name] = flat[off:off + n].view((bz,) + shp)
+            off += n
+        outs.append(o)
+    return outs
+
+
+def _mano_output_dict(outs, rot, shape, cam, cam_init, bz):
+    """Key order of mano_head.py:53-61 + the `cam_t.wp.init` / `mano.` prefixing of model.py:392-399."""
+    output = xdict()
+    for side, post in enumerate((".r", ".l")):
+        ro = side * bz
+        o = outs[side]
+        md = xdict()
+        md["cam_t.wp"] = cam[ro:ro + bz]
+        md["cam_t"] = o["cam_t"]
+        md["joints3d"] = o["joints3d"]
+        md["vertices"] = o["vertices"]
+        md["j3d.cam"] = o["j3d.cam"]
+        md["v3d.cam"] = o["v3d.cam"]
+        md["j2d.norm"] = o["j2d.norm"]
+        md["beta"] = shape[ro:ro + bz]
+        md["pose"] = rot[ro:ro + bz]
+        md = md.postfix(post)
+        md["cam_t.wp.init" + post] = cam_init[ro:ro + bz]       # model.py:392-393
+        output.merge(prefix_dict(md, "mano."))                  # model.py:395-399
+    return output
+
+
+class ManoHeadsPlan:
+    """``MANOHead.forward`` of both hands as ONE pre-bound C-ABI call (BASELINE configs[4], a serving loop over fixed
+    buffers): the descriptor array of ``hands_mano_heads_f32`` -- input pointers, the twelve output views, both assets'
+    constants -- is built once; ``launch(stream)`` is the single ctypes call per step and ``outputs`` the (fixed) result
+    dict.  The caller owns ``rot`` (2bz,16,3,3) [or (2bz,48) axis-angle with ``aa_input``], ``shape`` (2bz,10),
+    ``cam`` (2bz,3), ``K`` (bz,3,3) and rewrites them in place between steps."""
+
+    def __init__(self, L, mano_r, mano_l, rot, shape, cam, K, img_res, bz, aa_input=False, cam_init=None):
+        per = 48 if aa_input else 144
+        assert rot.is_contiguous() and shape.is_contiguous() and cam.is_contiguous() and K.is_contiguous()
+        assert rot.numel() == 2 * bz * per and shape.numel() == 2 * bz * 10 and cam.numel() == 2 * bz * 3 and K.numel() == bz * 9
+        self.L, self.bz, self.img_res, self.aa = L, bz, float(img_res), int(bool(aa_input))
+        self._keep = (mano_r, mano_l, rot, shape, cam, K)
+        self._outs = _mano_out_buffers(bz, rot.device)
+        self._sides = (ManoSide * 2)()
+        for side, mp in enumerate((mano_r, mano_l)):
+            ro, o = side * bz, self._outs[side]
+            mo = ManoOut(ptr(o["vertices"]), ptr(o["joints3d"]), ptr(o["v3d.cam"]), ptr(o["j3d.cam"]), ptr(o["j2d.norm"]),
+                         ptr(o["cam_t"]))
+            self._sides[side] = ManoSide(mp["consts"], ptr(mp["blend"].w), ptr(mp["blend"].bias), ptr(rot, ro * per),
+                                         ptr(shape, ro * 10), ptr(cam, ro * 3), mo)
+        self._K = ptr(K)
+        self.outputs = _mano_output_dict(self._outs, rot, shape, cam, cam if cam_init is None else cam_init, bz)
+
+    def launch(self, stream):
+        check(self.L.hands_mano_heads_f32(self._sides, 2, self._K, 10, self.img_res, 0.1, self.bz, self.aa, stream), "mano_heads")
+        return self.outputs
+
+
 def run_mano_heads(L, mano_r, mano_l, rot, shape, cam, cam_init, K, img_res, bz, stream, buf, engine=None):
     """MANOHead.forward for the right (rows [0,bz)) and left (rows [bz,2bz)) hands
     (src/nets/hand_heads/mano_head.py:21-65) + the `cam_t.wp.init` / `mano.` prefixing of
@@ -122,23 +195,7 @@ def run_mano_heads(L, mano_r, mano_l, rot, shape, cam, cam_init, K, img_res, bz,
     dev = rot.device
     engine = engine or DEFAULT_ENGINE
     fused = getattr(engine, "fuse_mano", True)
-    output = xdict()
-    # the twelve output tensors are contiguous views of ONE allocation (one allocator call per forward); the
-    # two vertex arrays come first in each side's 16-byte aligned block (the kernel stores them 8 bytes wide)
-    shapes = (("vertices", (778, 3)), ("v3d.cam", (778, 3)), ("joints3d", (21, 3)), ("j3d.cam", (21, 3)),
-              ("j2d.norm", (21, 2)), ("cam_t", (3,)))
-    side_floats = (bz * 4839 + 3) // 4 * 4
-    flat = torch.empty(2 * side_floats, device=dev)
-    outs = []
-    for side in range(2):
-        o, off = {}, side * side_floats
-        for name, shp in shapes:
-            n = bz
-            for d_ in shp:
-                n *= d_
-            o[name] = flat[off:off + n].view((bz,) + shp)
-            off += n
-        outs.append(o)
+    outs = _mano_out_buffers(bz, dev)
     mouts = [ManoOut(ptr(o["vertices"]), ptr(o["joints3d"]), ptr(o["v3d.cam"]), ptr(o["j3d.cam"]),
                      ptr(o["j2d.norm"]), ptr(o["cam_t"])) for o in outs]
     if fused:
@@ -160,23 +217,7 @@ def run_mano_heads(L, mano_r, mano_l, rot, shape, cam, cam_init, K, img_res, bz,
             check(L.hands_mano_skin_f32(C.byref(mp["consts"]), ptr(vposed), 2336, ptr(Abuf), ptr(j16),
                                         ptr(cam, ro * 3), ptr(K), img_res, 0.1, C.byref(mouts[side]), bz, stream),
                   "mano_skin")
-    for side, post in enumerate((".r", ".l")):
-        ro = side * bz
-        o = outs[side]
-        md = xdict()                                           # key order of mano_head.py:53-61
-        md["cam_t.wp"] = cam[ro:ro + bz]
-        md["cam_t"] = o["cam_t"]
-        md["joints3d"] = o["joints3d"]
-        md["vertices"] = o["vertices"]
-        md["j3d.cam"] = o["j3d.cam"]
-        md["v3d.cam"] = o["v3d.cam"]
-        md["j2d.norm"] = o["j2d.norm"]
-        md["beta"] = shape[ro:ro + bz]
-        md["pose"] = rot[ro:ro + bz]
-        md = md.postfix(post)
-        md["cam_t.wp.init" + post] = cam_init[ro:ro + bz]       # model.py:392-393
-        output.merge(prefix_dict(md, "mano."))                  # model.py:395-399
-    return output
+    return _mano_output_dict(outs, rot, shape, cam, cam_init, bz)
 
 
 run_mano_heads.launches_per_step = 1

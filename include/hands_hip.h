@@ -32,6 +32,10 @@ typedef void* hands_stream_t;
 
 int hands_abi_version(void);
 const char* hands_error_string(int code);
+/* 1 if `stream` is being captured into a hipGraph, 0 if not, < 0 = -(hipError_t).  The host side asks this about the
+ * stream it is about to LAUNCH on (torch's "current stream" is not necessarily that stream) before it takes a path that
+ * is illegal under capture: growing / zero-filling a workspace (hands_conv2d_nhwc_streamk_f32's epoch flags). */
+int hands_stream_is_capturing(hands_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution / linear layer as implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32).

@@ -25,7 +25,18 @@ def main():
     meta["is_flipped"] = (torch.arange(bz, device=dev) % 3 == 1).long()
     # "device": the gather takes the stream-ordered path RCCL takes (pending stream_xdict -> pack and collective on
     # a side stream, gloo staging the device tensors itself); default: host copies
+    import hands_amd.dist as dist_mod
+    from hands_amd.xdict import stream_xdict
     got = data_parallel_forward(model, inputs, meta, gather_on_host=on_host)
+    if not on_host:
+        # the forward's pending stream_xdict must reach gather_predictions UNJOINED, so that pack +
+        # collective run on the gather side stream behind the asynchronous tail; a rank with an empty shard is the
+        # one exception (it slices its stand-in row away)
+        from hands_amd.dist import shard_range
+        lo, hi = shard_range(bz, rank, world)
+        if hi > lo:
+            assert dev in dist_mod._gather_streams, "the stream-ordered gather path was not taken"
+            assert isinstance(got, stream_xdict) and got.is_pending
     if rank == 0:
         torch.save({k: v.detach().cpu().clone() for k, v in got.items()}, out_path)
     dist.barrier()

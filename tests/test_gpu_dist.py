@@ -65,3 +65,21 @@ def test_bench_launcher_starts_its_own_ranks():
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["global_batch"] == 16
     assert d["config"]["launched_by"] == "bench.py launcher" and d["value"] > 0
     assert d["roofline"]["kernel_ms_per_step"] <= d["roofline"]["step_ms_same_mode"]
+
+
+@pytest.mark.parametrize("workload,global_bz", [("handoccnet_light", 256), ("mano_lbs", 1024)])
+def test_bench_strong_scaling_dry_runs(workload, global_bz):
+    """`bench.py --workload handoccnet_light|mano_lbs --gpus 2`: the fixed-global-batch configs (BASELINE configs[3] /
+    [4]) split 256 / 1024 over the ranks ("scaling": "strong").  Dry run on the 1-GPU box: two ranks share cuda:0,
+    gloo stages the device tensors (the stream-ordered gather path RCCL takes)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(HANDS_BENCH_SHARE_GPU="1", HANDS_BENCH_BACKEND="gloo", HANDS_BENCH_GLOO_DEVICE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", workload, "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rccl_ranks"] == 2
+    assert d["config"]["global_batch"] == global_bz and d["config"]["per_gpu_batch"] == global_bz // 2
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0

@@ -328,46 +328,7 @@ def test_graphed_forward_and_frontend_refuse_cpu():
 
 
 # ---- real-asset loader (f3): chumpy-free MANO pickle reader -----------------------------------------
-def _write_fake_mano_pkl(path, asset, protocol=2):
-    """A pickle shaped like the licensed MANO_{RIGHT,LEFT}.pkl: a dict whose `shapedirs` (and here also
-    `v_template`, `posedirs`) are chumpy.ch.Ch objects -- a class NOT importable at load time --, whose
-    `J_regressor` is a scipy.sparse.csc_matrix, plus the keys smplx ignores."""
-    import pickle
-    import sys
-    import types
-    import scipy.sparse as sp
-
-    ch_mod = types.ModuleType("chumpy.ch")
-
-    class Ch(object):                          # chumpy.ch.Ch stores its value in the attribute `x`
-        def __init__(self, x):
-            self.x = np.asarray(x)
-            self._dirty_vars = set()
-            self._itr = None
-
-    Ch.__module__, Ch.__qualname__ = "chumpy.ch", "Ch"
-    ch_mod.Ch = Ch
-    pkg = types.ModuleType("chumpy")
-    pkg.ch = ch_mod
-    sys.modules["chumpy"], sys.modules["chumpy.ch"] = pkg, ch_mod
-    try:
-        d = {
-            "v_template": Ch(asset.v_template.astype(np.float64)),
-            "shapedirs": Ch(asset.shapedirs.astype(np.float64)),
-            "posedirs": Ch(asset.posedirs.T.reshape(778, 3, 135).astype(np.float64)),
-            "J_regressor": sp.csc_matrix(asset.J_regressor.astype(np.float64)),
-            "weights": asset.lbs_weights.astype(np.float64),
-            "hands_mean": asset.hands_mean.astype(np.float64),
-            "f": asset.faces.astype(np.uint32),
-            "kintree_table": np.stack([np.array([2 ** 32 - 1] + list(hands_amd.mano.PARENTS[1:]), dtype=np.int64),
-                                       np.arange(16)]),
-            "hands_components": np.eye(45), "hands_coeffs": np.zeros((10, 45)), "J": np.zeros((16, 3)),
-            "bs_style": "lbs", "bs_type": "lrotmin",
-        }
-        with open(path, "wb") as fh:
-            pickle.dump(d, fh, protocol=protocol)
-    finally:
-        del sys.modules["chumpy"], sys.modules["chumpy.ch"]
+from fake_mano import write_fake_mano_pkl as _write_fake_mano_pkl  # noqa: E402
 
 
 @pytest.mark.parametrize("is_rhand", [True, False])
@@ -434,3 +395,96 @@ def test_smplx_named_mano_buffers_load_from_a_reference_checkpoint(recipe_model)
     assert sorted(rep.unexpected_keys) == ["mano_r.mano.betas", "mano_r.mano.vertex_joint_selector.extra_joints_idxs"]
     assert torch.all(m.mano_r.mano.v_template == 0.5) and m._packed is None
     assert np.all(m.mano_r.mano.asset().v_template == 0.5)
+
+
+def test_hamer_pretrained_argument_has_the_reference_semantics(tmp_path, monkeypatch):
+    """src/models/hamer_light/model.py:33-44: ``args.get('pretrained', 'vit')``.  'vit' loads
+    $DATA_DIR/hamer_training_data/vitpose_backbone.pth['state_dict'] into ``backbone`` with strict=False,
+    'hamer' splits hamer.ckpt into ``backbone.`` / ``mano_head.`` and loads both strictly, a missing file
+    raises, anything else ('none') keeps the initial weights.  The synthetic checkpoints store every tensor as
+    an expanded one-element storage."""
+    import hands_amd.hamer as hamer_mod
+    from hands_amd.hamer import HAMER, _Args
+    monkeypatch.setattr(hamer_mod, "VIT_DEPTH", 3)          # the loader does not depend on the depth; keeps the test in seconds
+    mk = lambda **kw: _Args(pos_enc="center+corner_latent", n_freq_pos_enc=4, use_grasp_loss=True,
+                            use_render_seg_loss=False, **kw)
+    monkeypatch.setenv("DATA_DIR", str(tmp_path))
+    base = HAMER(mk(pretrained="none"))
+    fill = lambda t, v: torch.full((1,), v, dtype=t.dtype).expand(t.shape)
+    # -- a missing file raises (reference: torch.load fails), also when the key is absent (default 'vit')
+    with pytest.raises(FileNotFoundError):
+        HAMER(mk())
+    with pytest.raises(FileNotFoundError):
+        HAMER(mk(pretrained="hamer"))
+    monkeypatch.delenv("DATA_DIR")
+    with pytest.raises(KeyError):
+        HAMER(mk(pretrained="vit"))
+    monkeypatch.setenv("DATA_DIR", str(tmp_path))
+    # -- 'vit': ViTPose backbone file, strict=False: a subset of the keys + keys the model does not have
+    os.makedirs(tmp_path / "hamer_training_data")
+    vit_sd = {k: fill(v, 0.25) for k, v in base.backbone.state_dict().items() if not k.startswith("blocks.2.")}
+    vit_sd["keypoint_head.final_layer.weight"] = torch.zeros(17, 8)
+    torch.save({"state_dict": vit_sd, "meta": {"epoch": 210}}, tmp_path / "hamer_training_data" / "vitpose_backbone.pth")
+    m = HAMER(mk())                                         # no 'pretrained' key -> 'vit'
+    got = m.backbone.state_dict()
+    assert torch.all(got["blocks.0.attn.qkv.weight"] == 0.25) and torch.all(got["pos_embed"] == 0.25)
+    assert not torch.any(got["blocks.2.mlp.fc2.weight"] == 0.25)          # absent from the file: initial weights stay
+    assert not torch.all(m.mano_head.decpose.weight == 0.25) and m._packed is None
+    # -- 'hamer': strict on both halves
+    ck = tmp_path / "hamer" / "_DATA" / "hamer_ckpts" / "checkpoints"
+    os.makedirs(ck)
+    sd = {"backbone." + k: fill(v, 0.5) for k, v in base.backbone.state_dict().items()}
+    sd.update({"mano_head." + k: fill(v, 0.125) for k, v in base.mano_head.state_dict().items()})
+    sd["discriminator.D_shape.weight"] = torch.zeros(3)     # neither half: ignored, as in the reference
+    torch.save({"state_dict": sd}, ck / "hamer.ckpt")
+    m = HAMER(mk(pretrained="hamer"))
+    assert all(torch.all(v == 0.5) for v in m.backbone.state_dict().values())
+    assert all(torch.all(v == 0.125) for v in m.mano_head.state_dict().values())
+    assert not torch.all(m.kpe.feat_mlp[0].weight == 0.5)
+    del sd["backbone.blocks.1.norm1.bias"]
+    torch.save({"state_dict": sd}, ck / "hamer.ckpt")
+    with pytest.raises(RuntimeError, match="blocks.1.norm1.bias"):
+        HAMER(mk(pretrained="hamer"))
+    sd["backbone.blocks.1.norm1.bias"] = torch.zeros(1280)
+    sd["mano_head.extra.weight"] = torch.zeros(1)
+    torch.save({"state_dict": sd}, ck / "hamer.ckpt")
+    with pytest.raises(RuntimeError, match="extra.weight"):
+        HAMER(mk(pretrained="hamer"))
+
+
+def test_bench_launcher_stays_gpu_free_and_reports_the_failing_rank(monkeypatch, tmp_path):
+    """``python bench.py --gpus N`` (WORLD_SIZE unset) is a pure launcher -- it must not import torch
+    or touch the HIP runtime before (or after) starting its children; the GPU count comes from the *_VISIBLE_DEVICES lists
+    / sysfs.  A rank that dies is reported with the tail of ITS stderr.  Here (no GPU) every rank fails at
+    ``torch.cuda.set_device``: exactly the failure path."""
+    import importlib.util
+    import inspect
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    src = inspect.getsource(bench.launch_ranks) + inspect.getsource(bench.visible_gpu_count)
+    assert "import torch" not in src and "torch." not in src
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert bench.visible_gpu_count() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count() == 0
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 2 and "only 0 GPU(s) are visible" in p.stderr
+    env["HANDS_BENCH_SHARE_GPU"] = "1"           # skips the count check: the ranks start and fail on their own
+    env["HANDS_BENCH_BACKEND"] = "gloo"
+    probe = tmp_path / "sitecustomize.py"        # proves the launcher process itself never imported torch
+    probe.write_text("import atexit, os, sys\n"
+                     "if 'WORLD_SIZE' not in os.environ:\n"
+                     "    atexit.register(lambda: sys.stderr.write('LAUNCHER_TORCH=%s\\n' % ('torch' in sys.modules)))\n")
+    env["PYTHONPATH"] = str(tmp_path) + os.pathsep + env.get("PYTHONPATH", "")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode not in (0, 2), p.stderr[-1500:]
+    assert "LAUNCHER_TORCH=False" in p.stderr
+    assert "bench.py launcher: rank" in p.stderr and "stderr (tail)" in p.stderr and "Traceback" in p.stderr

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fold rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/r01_pmc_<workload>.json (dev tool).
-usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <workload> <out.json>
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <workload> <out.json> <bz>
 HBM bytes = 2 * FETCH_SIZE (KB; gfx950 reports half of a wide coalesced read stream, MI355X_MICROARCH.md
 section HBM) + WRITE_SIZE (KB), summed over every conv_igemm_f32_kernel dispatch of the run."""
 import csv
@@ -8,6 +8,7 @@ import json
 import sys
 
 fetch_csv, write_csv, workload, out = sys.argv[1:5]
+bz = int(sys.argv[5])          # samples per step the passes were taken at: bench.py refuses the summary at any other
 
 
 def total(fn, counter):
@@ -35,12 +36,12 @@ def by_grid(fn, counter):
 f, nf = total(fetch_csv, "FETCH_SIZE")
 w, nw = total(write_csv, "WRITE_SIZE")
 assert nf == nw and nf > 0, (nf, nw)
-res = {"workload": workload, "kernel": "conv_igemm_f32_kernel + conv_igemm_sk_f32_kernel", "dispatches": nf,
+res = {"workload": workload, "bz": bz, "kernel": "conv_igemm_f32_kernel + conv_igemm_sk_f32_kernel", "dispatches": nf,
        "fetch_size_kb_sum": f, "write_size_kb_sum": w, "fetch_correction": 2.0,
        "hbm_gb_per_launch": (2.0 * f + w) * 1024 / nf / 1e9,
        "read_gb_per_launch": 2.0 * f * 1024 / nf / 1e9, "write_gb_per_launch": w * 1024 / nf / 1e9,
        "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --workload {workload} "
-                  "--serial --steps 1 --warmup 1 --no-cpu-baseline"}
+                  f"--bz {bz} --serial --steps 1 --warmup 1 --no-cpu-baseline --no-also"}
 gf, gw = by_grid(fetch_csv, "FETCH_SIZE"), by_grid(write_csv, "WRITE_SIZE")
 res["by_launch_shape_gb_per_launch"] = {
     k: {"dispatches": gf[k][0], "read": round(2.0 * gf[k][1] * 1024 / gf[k][0] / 1e9, 4),
