@@ -284,6 +284,8 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         model.engine.math = os.environ["HANDS_MATH"]
     if os.environ.get("HANDS_ASYNC_TAIL") and hasattr(model, "async_tail"):
         model.async_tail = os.environ["HANDS_ASYNC_TAIL"] == "1"
+    if os.environ.get("HANDS_ASYNC_FORWARD") and hasattr(model, "async_forward"):      # developer A/B switch
+        model.async_forward = os.environ["HANDS_ASYNC_FORWARD"] == "1"
     model.overlap_trunks = not serial_headline
     if workload == "hands_light" and os.environ.get("HANDS_CHUNKS"):
         model.trunk_chunks = tuple(int(v) for v in os.environ["HANDS_CHUNKS"].split(","))

@@ -111,7 +111,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Same arithmetic as the general path: (acc + bias) + residual, then max(., 0).
 constexpr int EROW = 68;                            // 64 channels + 4 pad floats (17 slots: odd)
 constexpr int EPI_FLOATS = 4 * 32 * EROW;           // the epilogue's transposition buffers (one per wave) reuse the ring
-template <bool RELU, bool RES>
+template <int ACT, bool RES>
 __device__ __forceinline__ void epilogue_full(const f32x16 (&acc)[2][2], float* sE, int lane, const float* bias_p,
                                               const char* res_u, int res_ps, char* out_u, int out_ps) {
   // res_u / out_u: wave-uniform byte address of this wave's (pixel 0, channel 0); the lane part is one 32-bit
@@ -122,7 +122,9 @@ __device__ __forceinline__ void epilogue_full(const f32x16 (&acc)[2][2], float* 
   const uint32_t o_off = (uint32_t)((lane >> 4) * out_ps + (lane & 15) * 4) * 4u;
   const uint32_t r_off = (uint32_t)((lane >> 4) * res_ps + (lane & 15) * 4) * 4u;
   const float4 bv4 = *reinterpret_cast<const float4*>(bias_p);
+#ifndef HANDS_EPI_SCALAR_ADDS
   const f32x2 b01 = {bv4.x, bv4.y}, b23 = {bv4.z, bv4.w};
+#endif
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -140,6 +142,13 @@ __device__ __forceinline__ void epilogue_full(const f32x16 (&acc)[2][2], float* 
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const float4 t = *reinterpret_cast<const float4*>(rd + 4 * r * EROW);
+#ifdef HANDS_EPI_SCALAR_ADDS
+      // A/B variant (tools/build_variant.sh -DHANDS_EPI_SCALAR_ADDS): four scalar v_add_f32 per operand instead of two
+      // v_pk_add_f32 (MI355X_MICROARCH.md lists packed f32 VALU beside MFMAs as an anti-lever); same arithmetic
+      float4 v = make_float4(t.x + bv4.x, t.y + bv4.y, t.z + bv4.z, t.w + bv4.w);
+      if constexpr (RES) { v.x += rv[r].x; v.y += rv[r].y; v.z += rv[r].z; v.w += rv[r].w; }
+      asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));     // keep the SLP vectoriser from re-packing them
+#else
       f32x2 v01 = {t.x, t.y}, v23 = {t.z, t.w};
       v01 = v01 + b01;
       v23 = v23 + b23;
@@ -149,7 +158,8 @@ __device__ __forceinline__ void epilogue_full(const f32x16 (&acc)[2][2], float* 
         v23 = v23 + r23;
       }
       float4 v = make_float4(v01.x, v01.y, v23.x, v23.y);
-      if constexpr (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+#endif
+      if constexpr (ACT != HANDS_ACT_NONE) v = apply_act(v, ACT);       // compile-time activation: no runtime switch
       *reinterpret_cast<float4*>(out_u + (size_t)(j * 32 + 4 * r) * (size_t)out_ps * 4 + o_off) = v;
       // rows in pairs: without the fence the scheduler hoists all eight LDS reads (+32 live registers on top of
       // the 64 accumulators and 32 residual values: 160+ VGPRs, 3 waves per SIMD instead of 4)
@@ -472,18 +482,20 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
   const int n_lane = n0 + wn * 64 + c4 * 4;
   const bool n_ok = n_lane < a.N;
   const bool part = a.ksplit > 1;                   // split-K: raw partial sums, reduced by splitk_reduce_kernel
-  if (!part && a.relu <= HANDS_ACT_RELU && m0 + BM <= a.M && n0 + BN <= a.N) {      // (uniform) full tile, plain epilogue
+  if (!part && m0 + BM <= a.M && n0 + BN <= a.N) {      // (uniform) full tile: straight-line epilogue, activation compiled in
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int mw = m0 + (wave_u / WAVES_N) * 64, nw = n0 + (wave_u % WAVES_N) * 64;
     char* ou = reinterpret_cast<char*>(a.out) + ((size_t)mw * a.out_ps + nw) * 4;
     const char* ru = reinterpret_cast<const char*>(a.res) + ((size_t)mw * a.res_ps + nw) * 4;
-    if (a.relu == HANDS_ACT_RELU) {
-      if (a.res != nullptr) epilogue_full<true, true>(acc, sE, lane, a.bias + n_lane, ru, a.res_ps, ou, a.out_ps);
-      else                  epilogue_full<true, false>(acc, sE, lane, a.bias + n_lane, ru, a.res_ps, ou, a.out_ps);
-    } else {
-      if (a.res != nullptr) epilogue_full<false, true>(acc, sE, lane, a.bias + n_lane, ru, a.res_ps, ou, a.out_ps);
-      else                  epilogue_full<false, false>(acc, sE, lane, a.bias + n_lane, ru, a.res_ps, ou, a.out_ps);
-    }
+    const float* bp = a.bias + n_lane;
+#define HANDS_EPI(ACT)                                                                            \
+    if (a.res != nullptr) epilogue_full<ACT, true>(acc, sE, lane, bp, ru, a.res_ps, ou, a.out_ps); \
+    else                  epilogue_full<ACT, false>(acc, sE, lane, bp, ru, a.res_ps, ou, a.out_ps)
+    if (a.relu == HANDS_ACT_RELU) { HANDS_EPI(HANDS_ACT_RELU); }
+    else if (a.relu == HANDS_ACT_NONE) { HANDS_EPI(HANDS_ACT_NONE); }
+    else if (a.relu == HANDS_ACT_LEAKY_RELU) { HANDS_EPI(HANDS_ACT_LEAKY_RELU); }
+    else { HANDS_EPI(HANDS_ACT_GELU); }
+#undef HANDS_EPI
     return;
   }
   const float4 bv = part ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(a.bias + n_lane);

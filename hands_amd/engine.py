@@ -42,6 +42,7 @@ class ConvEngine:
                                       # stream-K / conv_igemm_splitk_f32_kernel = split-K + reduce / stem_pool_*)
         self._splitk_ws = {}          # (device, stream handle) -> workspace tensor
         self._sk_ws = {}              # (device, stream handle) -> [zeroed stream-K workspace, epoch counter]
+        self._capture_ws = {}         # split-K workspaces of launches recorded into a hipGraph (graph memory pool)
 
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
@@ -54,7 +55,7 @@ class ConvEngine:
         stream handle the launch went to: a model calls this when it drops its side streams (``invalidate_packed``,
         ``.to()``), so a later stream that happens to get a recycled handle starts from a fresh, zero-filled
         workspace and no destroyed stream keeps 64 MB pinned."""
-        for table in (self._splitk_ws, self._sk_ws):
+        for table in (self._splitk_ws, self._sk_ws, self._capture_ws):
             for key in [k for k in table if dev is None or k[0] == dev]:
                 del table[key]
 
@@ -68,17 +69,19 @@ class ConvEngine:
 
     def _workspace(self, L, dev, stream, need):
         key = (dev, stream)
-        ws = self._splitk_ws.get(key)
+        capturing = self._capturing(L, stream)
+        # a launch recorded into a hipGraph gets a workspace from the graph's own memory pool (torch allocates from it
+        # during capture) and never shares one with eager launches: the capture stream's handle can be recycled
+        table = self._capture_ws if capturing else self._splitk_ws
+        ws = table.get(key)
         if ws is None or ws.numel() < need:
-            if self._capturing(L, stream):
-                raise RuntimeError("hands_amd: a split-K workspace has to grow inside a hipGraph capture; run one eager "
-                                   "forward at this batch size first (GraphedForward does)")
-            if ws is not None:
+            if ws is not None and not capturing:
                 # a kernel on a raw side-stream handle may still read the old block, and the caching
                 # allocator only knows torch's current stream: drain before dropping it (growth is rare --
-                # the first forward at a new batch size)
+                # the first forward at a new batch size).  (Under capture a larger block is simply recorded as a new
+                # allocation of the graph pool; synchronising would be illegal there.)
                 torch.cuda.synchronize(dev)
-            ws = self._splitk_ws[key] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=dev)
+            ws = table[key] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=dev)
         return ws
 
     def conv(self, L, pc, x, B, H, W, out, relu, stream, res=None, in_ps=None, out_ps=None, res_ps=None,

@@ -28,7 +28,7 @@ from .engine import ConvEngine, EngineSwitches
 from .hands_light import MANOHead, _Args, mano_consts, run_mano_heads
 from .packing import BN_EPS, PackedConv, fold_bn, pack_conv, pack_linear, pack_mano
 from .param_tree import build_tree, load_manifest
-from .xdict import xdict
+from .xdict import stream_xdict, xdict
 
 HANDOCC_DEFAULT_ARGS = _Args(pos_enc="center+corner_latent", n_freq_pos_enc=4, use_grasp_loss=True,
                              use_render_seg_loss=False, img_res=224, focal_length=1000.0,
@@ -85,6 +85,11 @@ class HandOccNet(EngineSwitches, nn.Module):
         self.engine = ConvEngine()
         self.small_map_splitk = True   # call-site constant split-K on maps of <= 8x8 pixels (see _conv_fns)
         self.chunks = 2   # the 2*bz crops run as this many jobs on separate HIP streams (1 = single stream)
+        self.async_forward = True   # two forwards in flight: call i runs on pipeline stream i & 1 and is joined at the first
+                                    # use of its result (stream_xdict), so the launches of consecutive calls fill each other's
+                                    # tails -- at 32 samples per GPU a launch is 1-4 tiles per CU, all in phase when alone
+        self._calls = 0
+        self._pipe_done = {}
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_packed())
 
     def _side_stream(self, dev, i):
@@ -219,18 +224,50 @@ class HandOccNet(EngineSwitches, nn.Module):
         assert c == 3 and l_img.shape == r_img.shape and K.shape[1:] == (3, 3)
         B2 = 2 * bz
         P = self.packed(dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        main = torch.cuda.current_stream(dev)
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
-
-        # -- model.py:66-70: resize to 256x256, cat(r, l) -> NHWC4 ---------------------------------
+        # -- everything that READS the caller's tensors runs on the caller's stream: the caller may overwrite its inputs
+        #    as soon as forward returns -----------------------------------------------------------------------------
+        # model.py:66-70: resize to 256x256, cat(r, l) -> NHWC4
         S = 256
         x4 = new(B2, S, S, 4)
         for side, im in enumerate((r_img, l_img)):
             check(L.hands_resize_crop_nchw3_to_nhwc4_f32(ptr(im), ptr(x4, side * bz * S * S * 4), bz, Hin, Win, S, 0, S,
-                                                         stream), "resize")
-        # -- KPE embedding (hamer_light/pos_emb.py:28-64, feat_dim 256) ----------------------------
+                                                         main.cuda_stream), "resize")
+        # KPE angles (hamer_light/pos_emb.py:28-64, feat_dim 256): private copies
         center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
         corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0)
+        dbg = self.__dict__.get("_debug")
+        pipelined = bool(self.async_forward and self.engine.overlap and dbg is None and self.engine.hook is None
+                         and not self.engine._capturing(L, main.cuda_stream))
+        if pipelined:
+            par = self._calls & 1
+            self._calls += 1
+            st = self._side_stream(dev, f"pipe{par}")
+            K = K.clone()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            st.wait_event(ev)
+            for t in (x4, center, corner, K):
+                t.record_stream(st)
+        else:
+            st = main
+            for evd in self._pipe_done.values():     # a synchronous call is ordered after every forward still in flight
+                main.wait_event(evd)
+        with torch.cuda.stream(st):
+            output = self._forward_body(L, P, dev, x4, center, corner, K, bz)
+        if not pipelined:
+            return output
+        ready = torch.cuda.Event()
+        ready.record(st)
+        self._pipe_done[par] = ready
+        return stream_xdict(output, ready, dev)
+
+    def _forward_body(self, L, P, dev, x4, center, corner, K, bz):
+        """Everything after the input resize (model.py:72-129), enqueued on torch's CURRENT stream."""
+        B2, S = 2 * bz, 256
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
 
         conv, hconv = _conv_fns(L, stream, new, self.engine, self.small_map_splitk)
 

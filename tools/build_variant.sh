@@ -16,7 +16,7 @@ else
 fi
 if [ -n "$REPL" ]; then cp $REPL $D/${4:-conv_igemm.hip}; fi
 cd $D
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I. -fno-fast-math -ffp-contract=off -Wno-unused-function"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I. -fno-fast-math -ffp-contract=off -Wno-unused-function $EXTRA_FLAGS"   # EXTRA_FLAGS: e.g. -DHANDS_EPI_SCALAR_ADDS
 OBJS=""
 for f in *.hip; do /opt/rocm/bin/hipcc $FLAGS -c $f -o ${f%.hip}.o & OBJS="$OBJS ${f%.hip}.o"; done
 wait
