@@ -219,30 +219,87 @@ __global__ void __launch_bounds__(256) spatial_softmax_kernel(const float* __res
 }
 
 // ---- flash attention on fp32 MFMA: N tokens (multiple of 128), head dim 64 ---------------------------
-// grid (N/128, heads, B); 4 waves x 32 queries.  Loop over key tiles of 128 with online softmax
-// (running max / sum per query, lane-local + one exchange with lane^32), S^T = K (scale applied after
-// the product, transformer.py:81) and O^T = V^T P exactly as in transformer.hip's attention_kernel.
+// 1-D grid of B * heads * N/128 workgroups (XCD-aware order: the N/128 query chunks of one (crop, head) run on ONE
+// XCD, so its K / V rows are fetched into one L2 instead of eight); 4 waves x 32 queries.  Loop over key tiles of
+// 128 with online softmax (running max / sum per query, lane-local + one exchange with lane^32), S^T = K Q^T and
+// O^T = V^T P as in transformer.hip's attention_kernel: the probabilities feed the second product straight from the
+// accumulator registers.
+//   * K and V tiles (32 KB each, single-buffered) arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers,
+//     no ds_write pass).  The DMA destination is lane-linear, so the K tile's 16-byte chunk c of key row r is FETCHED by
+//     the lane whose slot is c ^ (r & 15) (swizzle on the source address) and read back with the same XOR: the
+//     ds_read_b128 fragment reads (32 rows, one chunk column) are bank-conflict free.  V stays row-major [key][64] and is
+//     read as the A operand with conflict-free 32-bit reads (lanes 0-31 = 32 consecutive d of one key): no transpose.
+//   * Two barriers per key tile, each preceded by vmcnt(0): V(t) is issued when every wave has finished P V(t-1) and
+//     flies under Q K^T(t); K(t+1) is issued when every wave has finished Q K^T(t) and flies under softmax + P V(t).
+//   * FOLD: scale is a power of two (64^-0.5 = 0.125), so q * scale is exact and (q k) * scale of transformer.py:81
+//     equals (q * scale) k bit for bit: the 64 multiplies per lane and key tile disappear.  exp(x), x <= 0, is
+//     exp2 of a compensated x * log2(e) (v_exp_f32 on [-0.5, 0.5] + v_ldexp_f32: ~1 ulp, 7 instructions instead of
+//     the library's 13 with its range checks).
 // Epilogue: O / l, optional FIT gate sigmoid((q2 . sum_j k2_j) * scale) (transformer.py:84-90, the key
 // sum hoisted out of the N x N product), optional residual (SET: query + attn).
-__global__ void __launch_bounds__(256) flash_attention64_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                                const float* __restrict__ v, const float* __restrict__ q2,
-                                                                const float* __restrict__ k2sum, const float* __restrict__ resid,
-                                                                float* __restrict__ out, int N, int heads, float scale) {
-  constexpr int D = 64, KT = 128, KR = D + 4, VR = KT + 4;
-  __shared__ __attribute__((aligned(16))) float lds[KT * KR + D * VR];
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+__device__ __forceinline__ float exp_nonpos(float x) {     // x <= 0, finite
+  const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;
+  const float n = rintf(x * L2E_HI);
+  float f = fmaf(x, L2E_HI, -n);                           // x * log2(e) - n with one rounding
+  f = fmaf(x, L2E_LO, f);
+  return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
+template <bool FOLD>
+__global__ void __launch_bounds__(256, 2) flash_attention64_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                   const float* __restrict__ v, const float* __restrict__ q2,
+                                                                   const float* __restrict__ k2sum, const float* __restrict__ resid,
+                                                                   float* __restrict__ out, int N, int heads, float scale) {
+  constexpr int D = 64, KT = 128;
+  __shared__ __attribute__((aligned(1024))) float lds[2 * KT * D];
   float* sK = lds;
-  float* sV = lds + KT * KR;
-  const int qc = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  float* sV = lds + KT * D;
+  // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs; give each XCD a contiguous range
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int qd = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = ((xcd < r) ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + idx;
+  }
+  const int nq = N / 128;
+  const int qc = bid % nq, h = (bid / nq) % heads, b = bid / (nq * heads);
   const int C = heads * D;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
   const long long row0 = (long long)b * N;
   const int qrow = qc * 128 + wave * 32 + (lane & 31);
+
+  // DMA source of this lane for piece i (4 key rows = 1 KB) of this wave's 8 pieces of a tile: LDS position p = lane
+  // -> row 4 * (8 wave + i) + (lane >> 4), slot lane & 15
+  const int r_in = lane >> 4, slot = lane & 15;
+  const float* kb0 = k + row0 * C + h * D;
+  const float* vb0 = v + row0 * C + h * D;
+  // source address = wave-uniform row base (scalar) + a 32-bit lane offset; (r & 15) = 4 (i & 3) + r_in, so the K tile
+  // needs four lane offsets and the V tile one
+  int koff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) koff[i] = r_in * C + ((slot ^ (4 * i + r_in)) << 2);
+  const int voff = r_in * C + (slot << 2);
+#define ISSUE_TILE(BASE, DST, KTI, SWZ)                                                                          \
+  do {                                                                                                            \
+    const float* ub = (BASE) + (long long)((KTI) * KT + wave * 32) * C;                                           \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                 \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(ub + i * 4 * C + ((SWZ) ? koff[i & 3] : voff)),              \
+                                       (lds_void_t*)((DST) + (wave * 8 + i) * 256), 16, 0, 0);                    \
+  } while (0)
+
+  ISSUE_TILE(kb0, sK, 0, true);
 
   float4 qf[D / 8];
   {
     const float* qp = q + (row0 + qrow) * C + h * D + half * 4;
 #pragma unroll
-    for (int kk = 0; kk < D / 8; ++kk) qf[kk] = *reinterpret_cast<const float4*>(qp + kk * 8);
+    for (int kk = 0; kk < D / 8; ++kk) {
+      qf[kk] = *reinterpret_cast<const float4*>(qp + kk * 8);
+      if constexpr (FOLD) { qf[kk].x *= scale; qf[kk].y *= scale; qf[kk].z *= scale; qf[kk].w *= scale; }
+    }
   }
   f32x16 o[2];
 #pragma unroll
@@ -250,22 +307,14 @@ __global__ void __launch_bounds__(256) flash_attention64_kernel(const float* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float m = -INFINITY, l = 0.f;
+  const int swz = lane & 15;                                  // (key row & 15) of this lane's fragment rows
+  const float* vrd = sV + (lane & 31) + half * 4 * D;         // A operand of P V: V[key][db * 32 + (lane & 31)]
+  const int ntile = N / KT;
 
-  for (int kt = 0; kt < N / KT; ++kt) {
-    __syncthreads();   // previous tile fully consumed
-    const float* kb = k + (row0 + kt * KT) * C + h * D;
-    const float* vb = v + (row0 + kt * KT) * C + h * D;
-    for (int i = tid; i < KT * (D / 4); i += 256) {
-      const int t = i / (D / 4), dq = i - t * (D / 4);
-      *reinterpret_cast<float4*>(sK + t * KR + dq * 4) = *reinterpret_cast<const float4*>(kb + (long long)t * C + dq * 4);
-    }
-    for (int i = tid; i < KT * (D / 4); i += 256) {
-      const int t = i % KT, dq = i / KT;
-      const float4 vv = *reinterpret_cast<const float4*>(vb + (long long)t * C + dq * 4);
-      sV[(dq * 4 + 0) * VR + t] = vv.x; sV[(dq * 4 + 1) * VR + t] = vv.y;
-      sV[(dq * 4 + 2) * VR + t] = vv.z; sV[(dq * 4 + 3) * VR + t] = vv.w;
-    }
-    __syncthreads();
+  for (int kt = 0; kt < ntile; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // K(kt) has landed (this wave's pieces) ...
+    __syncthreads();                                          // ... everybody's; and every wave is done with V(kt-1)
+    ISSUE_TILE(vb0, sV, kt, false);                           // flies under Q K^T
 
     f32x16 s[4];
     float tmax = -INFINITY;
@@ -273,17 +322,24 @@ __global__ void __launch_bounds__(256) flash_attention64_kernel(const float* __r
     for (int kbk = 0; kbk < 4; ++kbk) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kbk][r] = 0.f;
-      const float* krow = sK + (kbk * 32 + (lane & 31)) * KR + half * 4;
+      const float* krow = sK + (kbk * 32 + (lane & 31)) * D;
 #pragma unroll
       for (int kk = 0; kk < D / 8; ++kk) {
-        const float4 kf = *reinterpret_cast<const float4*>(krow + kk * 8);
+        const float4 kf = *reinterpret_cast<const float4*>(krow + (((2 * kk + half) ^ swz) << 2));
 #pragma unroll
         for (int t = 0; t < 4; ++t)
           s[kbk] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(kf, t), f4e(qf[kk], t), s[kbk], 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[kbk][r] *= scale; tmax = fmaxf(tmax, s[kbk][r]); }
+      for (int r = 0; r < 16; ++r) {
+        if constexpr (!FOLD) s[kbk][r] *= scale;
+        tmax = fmaxf(tmax, s[kbk][r]);
+      }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // V(kt) has landed ...
+    __syncthreads();                                          // ... everybody's; and every wave is done with K(kt)
+    if (kt + 1 < ntile) ISSUE_TILE(kb0, sK, kt + 1, true);    // flies under softmax + P V
+
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float mnew = fmaxf(m, tmax);
     const float alpha = expf(m - mnew);     // first tile: exp(-inf) = 0
@@ -291,7 +347,7 @@ __global__ void __launch_bounds__(256) flash_attention64_kernel(const float* __r
 #pragma unroll
     for (int kbk = 0; kbk < 4; ++kbk)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[kbk][r] = expf(s[kbk][r] - mnew); psum += s[kbk][r]; }
+      for (int r = 0; r < 16; ++r) { s[kbk][r] = exp_nonpos(s[kbk][r] - mnew); psum += s[kbk][r]; }
     psum += __shfl_xor(psum, 32);
     l = l * alpha + psum;
     m = mnew;
@@ -302,19 +358,16 @@ __global__ void __launch_bounds__(256) flash_attention64_kernel(const float* __r
 #pragma unroll
     for (int kbk = 0; kbk < 4; ++kbk) {
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        float4 vf[2];
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-          vf[db] = *reinterpret_cast<const float4*>(sV + (db * 32 + (lane & 31)) * VR + kbk * 32 + q4 * 8 + half * 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int db = 0; db < 2; ++db)
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(vf[db], i), s[kbk][q4 * 4 + i], o[db], 0, 0, 0);
+      for (int r = 0; r < 16; ++r) {
+        // register r of block kbk holds P for key kbk * 32 + 8 (r >> 2) + (r & 3) + 4 half
+        const float* vp = vrd + (kbk * 32 + 8 * (r >> 2) + (r & 3)) * D;
+        const float a0 = vp[0], a1 = vp[32];
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, s[kbk][r], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[kbk][r], o[1], 0, 0, 0);
       }
     }
   }
+#undef ISSUE_TILE
 
   float gate = 1.0f;
   if (q2) {
@@ -430,8 +483,16 @@ int hands_flash_attention_f32(const float* q, const float* k, const float* v, co
                               const float* resid, float* out, int B, int N, int heads, int head_dim, float scale,
                               hands_stream_t stream) {
   if (!q || !k || !v || !out || B <= 0 || heads <= 0 || head_dim != 64 || N % 128 || (q2 && !k2sum)) return HANDS_EINVAL;
-  hipLaunchKernelGGL(flash_attention64_kernel, dim3(N / 128, heads, B), dim3(256), 0, S(stream), q, k, v, q2, k2sum,
-                     resid, out, N, heads, scale);
+  const long long nwg = (long long)B * heads * (N / 128);
+  if (nwg > 0x7fffffffLL) return HANDS_EINVAL;
+  // scale a power of two (head_dim 64 -> 0.125): folded into q exactly; any other value is applied after the product
+  const bool pow2 = scale > 0.f && (__builtin_bit_cast(unsigned, scale) & 0x007fffffu) == 0u && scale >= 1e-30f;
+  if (pow2)
+    hipLaunchKernelGGL(flash_attention64_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, S(stream), q, k, v, q2, k2sum,
+                       resid, out, N, heads, scale);
+  else
+    hipLaunchKernelGGL(flash_attention64_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, S(stream), q, k, v, q2, k2sum,
+                       resid, out, N, heads, scale);
   HANDS_LAUNCH_CHECK();
 }
 
