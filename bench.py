@@ -284,6 +284,8 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         model.engine.math = os.environ["HANDS_MATH"]
     if os.environ.get("HANDS_ASYNC_TAIL") and hasattr(model, "async_tail"):
         model.async_tail = os.environ["HANDS_ASYNC_TAIL"] == "1"
+    if os.environ.get("HANDS_FUSE_LINK"):          # developer A/B switch
+        model.engine.fuse_link = os.environ["HANDS_FUSE_LINK"] == "1"
     if os.environ.get("HANDS_ASYNC_FORWARD") and hasattr(model, "async_forward"):      # developer A/B switch
         model.async_forward = os.environ["HANDS_ASYNC_FORWARD"] == "1"
     model.overlap_trunks = not serial_headline
@@ -341,7 +343,9 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         if phase == "begin":
             macs = pc.macs_per_pixel * npix
             # algorithmic bytes: input read once + output written once (+ residual read) + weights once
-            if kernel.startswith("stem_pool"):    # image in (RGB0 NHWC4, or the 3 NCHW planes), pooled 64-channel map out
+            if getattr(pc, "alg_bytes_per_pixel", None):     # fused conv3 -> conv1 launch: its own byte count
+                nbytes = pc.alg_bytes_per_pixel * npix + 4.0 * pc.w.numel()
+            elif kernel.startswith("stem_pool"):    # image in (RGB0 NHWC4, or the 3 NCHW planes), pooled 64-channel map out
                 nbytes = 4.0 * (npix * 4 * (3 if "planar" in kernel else 4) + (npix // 4) * 64 + pc.w.numel())
             else:
                 nbytes = 4.0 * (npix * pc.Cout * (2 if has_res else 1) + npix * pc.stride * pc.stride * pc.Cin + pc.w.numel())
@@ -381,7 +385,7 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
     k_flop = sum(d["flop"] for d in per.values()) / n_prof
     achieved = k_flop / (k_ms * 1e-3) / 1e12
     # the GEMM / convolution family (plain, stream-K and split-K launches of conv_igemm): what the PMC summaries cover
-    fam = [d for k, d in per.items() if k.startswith("conv_igemm")]
+    fam = [d for k, d in per.items() if k.startswith(("conv_igemm", "bottleneck_link"))]
     fam_launches = sum(d["launches"] for d in fam)
     fam_alg_gb = sum(d["bytes"] for d in fam) / max(fam_launches, 1) / 1e9
     traffic, traffic_src = pmc_traffic_per_launch(workload, bz)

@@ -57,6 +57,7 @@ class EvalOut(C.Structure):
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
     "hands_conv2d_nhwc_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P],
+    "hands_bottleneck_link_f32": [_P, _P, _P, _P, _P, _P, _P, _P, C.c_longlong, _I, _P],
     "hands_conv2d_splitk_factor": [C.POINTER(ConvDesc)],
     "hands_conv2d_nhwc_splitk_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_longlong, _P],
     "hands_conv2d_streamk_grid": [C.POINTER(ConvDesc)],

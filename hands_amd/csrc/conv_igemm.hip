@@ -201,8 +201,21 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
   const int wm = wave / WAVES_N;            // wave row (pixels)
   const int wn = wave % WAVES_N;            // wave col (channels)
 
+#ifdef HANDS_RASTER_GM
+  // A/B variant (tools/build_variant.sh -DHANDS_RASTER_GM=8): bands of GM m-tiles, m fastest inside a band, so that the
+  // tiles resident on an XCD at one time form a GM x (128 / GM) block of the output instead of 4 m-rows x all n-tiles
+  int mt, nt;
+  if (a.nblk_n >= 8 && a.nblk_m >= HANDS_RASTER_GM) {
+    const int per = HANDS_RASTER_GM * a.nblk_n;
+    const int gidx = tile / per, idx = tile - gidx * per;
+    const int gm = min(HANDS_RASTER_GM, a.nblk_m - gidx * HANDS_RASTER_GM);
+    nt = idx / gm; mt = gidx * HANDS_RASTER_GM + (idx - nt * gm);
+  } else { mt = tile / a.nblk_n; nt = tile - mt * a.nblk_n; }
+  const int m0 = mt * BM, n0 = nt * BN;
+#else
   const int m0 = (tile / a.nblk_n) * BM;    // n fastest: consecutive tiles share the pixel rows
   const int n0 = (tile % a.nblk_n) * BN;
+#endif
 
   // ---- per-thread staging assignment: row = (tid>>2) + 64*i, 16-byte chunk = tid&3 ------------
   const int srow = tid >> 2;

@@ -254,6 +254,12 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
   const int B = a.B;
 
   // ---- phase 1: pose, joints, forward kinematics: thread = (hand h or h + 16, joint j) ----------------------
+#if defined(HANDS_MANO_ABL) && HANDS_MANO_ABL == 1      // timing-only ablation (tools/build_variant.sh): no pose / FK
+  for (int e = tid; e < MH * BROW; e += 256) (&sBin[0][0])[e] = 0.f;
+  for (int e = tid; e < MH * NJ * 12; e += 256) (&sA[0][0])[e] = 0.f;
+  if (tid < MH * 3) (&sCam[0][0])[tid] = 0.f;
+  __syncthreads();
+#else
   {
     const int j = tid & 15;
     float Rloc[MH / 16][9];                          // this thread's local joint rotations (one per hand it owns)
@@ -370,6 +376,7 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
     }
     __syncthreads();      // sA complete; the scratch (sR, sJ, sG) is free for the v_posed stage from here on
   }
+#endif
 
   // ---- phase 2 + 3 per chunk --------------------------------------------------------------------------------
   const int lane = tid & 63, wave = tid >> 6;

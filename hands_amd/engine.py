@@ -36,6 +36,12 @@ class ConvEngine:
                                       # reported mode: operands split into three exact bf16 planes, six bf16 MFMAs per
                                       # k-16 step with fp32 accumulation (HANDS_MATH_BF16X3); never the headline
         self.fuse_mano = True         # MANOHead.forward of both hands as one launch (hands_mano_heads_f32)
+        self.fuse_link = False        # layer1: conv3 + identity + ReLU of block i and conv1 + ReLU of block i + 1 as one
+                                      # launch (hands_bottleneck_link_f32): `out` is not re-read from HBM; bit-identical.
+                                      # Built and measured (profiles/README.md, round 3): its 64-pixel x 256-channel LDS tile
+                                      # and ~230 VGPRs allow 2 waves per SIMD, and the memory phase of a tile does not overlap
+                                      # its two MFMA phases: 4.8 ms per forward against 4.0 ms for the separate launches
+                                      # (4 waves per SIMD).  Kept as an opt-in and as the tested reference of the seam.
         self.hook = None              # callable(phase, pc, npix, stream_handle, has_res, kernel): bench.py brackets
                                       # every MFMA launch (conv_igemm and the fused stem) with events; `kernel` is the
                                       # kernel the launch really runs (conv_igemm_f32_kernel / conv_igemm_sk_f32_kernel =
@@ -46,7 +52,7 @@ class ConvEngine:
 
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
-        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "fuse_mano", "stream_k", "math"):
+        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "fuse_mano", "fuse_link", "stream_k", "math"):
             setattr(e, k, getattr(self, k))
         return e
 
@@ -148,6 +154,23 @@ class ConvEngine:
         if hook is not None:
             hook("end", pc, B * Ho * Wo, stream, False, "conv_igemm_f32_kernel")
 
+    @staticmethod
+    def link_ok(c3, c1, npix):
+        """Can conv3 (+identity, ReLU) of one bottleneck and conv1 (ReLU) of the next run as hands_bottleneck_link_f32?"""
+        return (c3.KH == 1 and c3.KW == 1 and c3.stride == 1 and c3.pad == 0 and c3.Cin == 64 and c3.Kpad == 64 and c3.Cout == 256
+                and c1.KH == 1 and c1.KW == 1 and c1.stride == 1 and c1.pad == 0 and c1.Cin == 256 and c1.Kpad == 256
+                and c1.Cout in (64, 128) and npix % 64 == 0)
+
+    def bottleneck_link(self, L, c3, c1, t2, ident, out, t1, npix, stream, out_off=0):
+        """out = relu(conv3(t2) + identity), t1 = relu(conv1(out)) in one launch (resnet.py:146-154 + 137-139)."""
+        hook = self.hook
+        if hook is not None:
+            hook("begin", _LinkPC(c3, c1), npix, stream, True, "bottleneck_link_kernel")
+        check(L.hands_bottleneck_link_f32(ptr(t2), ptr(c3.w), ptr(c3.bias), ptr(ident), ptr(out, out_off), ptr(c1.w), ptr(c1.bias),
+                                          ptr(t1), npix, c1.Cout, stream), "hands_bottleneck_link_f32")
+        if hook is not None:
+            hook("end", _LinkPC(c3, c1), npix, stream, True, "bottleneck_link_kernel")
+
     def stem_pool(self, L, pc, x4, x_off, out, B, H, W, act, stream):
         """conv 7x7/2 + folded BN + act + max-pool 3x3/2 in one kernel (resnet.py:264-268); the conv map
         (B, Hc, Wc, 64) never reaches HBM.  Returns the conv map size (Hc, Wc)."""
@@ -173,6 +196,25 @@ class ConvEngine:
         if hook is not None:
             hook("end", pc, B * Hc * Wc, stream, False, "stem_pool_planar_kernel")
         return Hc, Wc
+
+
+class _LinkPC:
+    """What bench.py's launch hook reads, for the fused conv3 -> conv1 launch: algorithmic work of BOTH layers."""
+
+    def __init__(self, c3, c1):
+        self.Cin, self.Cout, self.KH, self.KW, self.stride = c3.Cin, c3.Cout, 1, 1, 1
+        self.macs_per_pixel = c3.macs_per_pixel + c1.macs_per_pixel
+        # bytes per pixel: t2 in, identity in, out, t1 out (+ both weight matrices once per launch)
+        self.alg_bytes_per_pixel = 4.0 * (c3.Cin + 2 * c3.Cout + c1.Cout)
+        self.w = _Numel(c3.w.numel() + c1.w.numel())
+
+
+class _Numel:
+    def __init__(self, n):
+        self._n = n
+
+    def numel(self):
+        return self._n
 
 
 DEFAULT_ENGINE = ConvEngine()

@@ -453,11 +453,14 @@ class HandsLight(EngineSwitches, nn.Module):
         """A run of bottlenecks (resnet.py:134-154) on ping-pong buffers; the last one writes ``final_dst``
         at float offset ``final_off``.  Returns (H, W) of the output map."""
         n = len(blocks)
+        linked = False          # this block's conv1 was already computed by the previous block's fused launch
         for i, e in enumerate(blocks):
-            self.engine.conv(L, e["c1"], cur, B, H, W, t1, True, stream)
+            if not linked:
+                self.engine.conv(L, e["c1"], cur, B, H, W, t1, True, stream)
             H2, W2 = self.engine.conv(L, e["c2"], t1, B, H, W, t2, True, stream)
             last = i + 1 == n
             dst, off = (final_dst, final_off) if last else (nxt, 0)
+            linked = False
             if "ds" in e and self.engine.fuse_downsample:
                 self.engine.conv_dual(L, e["c3ds"], e["c3ds_split"], t2, cur, B, H2, W2, H, W, dst, stream, out_off=off)
             else:
@@ -466,7 +469,14 @@ class HandsLight(EngineSwitches, nn.Module):
                     ident = ds
                 else:
                     ident = cur
-                self.engine.conv(L, e["c3"], t2, B, H2, W2, dst, True, stream, res=ident, out_off=off)
+                if (not last and self.engine.fuse_link and self.engine.math == "fp32" and "ds" not in e
+                        and self.engine.link_ok(e["c3"], blocks[i + 1]["c1"], B * H2 * W2)):
+                    # conv3 + identity + ReLU, and the NEXT block's conv1 + ReLU on the tile while it is still in LDS
+                    # (t1 is free: this block's conv2 has consumed it, in stream order)
+                    self.engine.bottleneck_link(L, e["c3"], blocks[i + 1]["c1"], t2, ident, dst, t1, B * H2 * W2, stream, out_off=off)
+                    linked = True
+                else:
+                    self.engine.conv(L, e["c3"], t2, B, H2, W2, dst, True, stream, res=ident, out_off=off)
             H, W = H2, W2
             cur, nxt = dst, cur
         return H, W

@@ -83,6 +83,16 @@ int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, const float
                           const float* bias, const float* residual, float* out,
                           hands_stream_t stream);
 
+/* The seam between two bottlenecks of layer1 as ONE launch (csrc/bottleneck_link.hip):
+ *     out = relu(conv3_1x1(t2) + bn3 + identity)     src/nets/backbone/resnet.py:146-154 of block i     (64 -> 256)
+ *     t1  = relu(conv1_1x1(out) + bn1)               src/nets/backbone/resnet.py:137-139 of block i + 1 (256 -> C1)
+ * t2 (M,64), identity / out (M,256), t1 (M,C1), all NHWC with the channel count as pixel stride; w3_packed / bias3 and
+ * w1_packed / bias1 are hands_pack_conv_f64 outputs of the two layers (BatchNorm folded).  M % 64 == 0, C1 in {64, 128}.
+ * `out` never comes back from HBM for the second product.  Bit-identical to hands_conv2d_nhwc_f32 called twice. */
+int hands_bottleneck_link_f32(const float* t2, const float* w3_packed, const float* bias3, const float* identity,
+                              float* out, const float* w1_packed, const float* bias1, float* t1, long long M, int C1,
+                              hands_stream_t stream);
+
 /* Deterministic split-K form of the same layer for latency-bound GEMMs (1x1 / linear layers with few
  * rows and a long K: the HMR / decoder / regressor heads).  hands_conv2d_splitk_factor() returns the
  * number of K slices S the library would use (1 = no split): S = min(8, Kpad/256) for linear layers

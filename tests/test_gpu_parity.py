@@ -904,3 +904,49 @@ def test_wrapper_inference_contract(gpu_model):
     assert out["pred.mano.vertices.r"].device.type == "cpu" and out["inputs.img"].device.type == "cpu"
     assert out["meta_info.imgname"] == ["a.jpg", "b.jpg"]
     assert sum(k.startswith("pred.") for k in out) == 22
+
+
+@pytest.mark.parametrize("C1", [64, 128])
+@pytest.mark.parametrize("B", [2, 37])
+def test_bottleneck_link_is_bit_identical(C1, B):
+    """hands_bottleneck_link_f32: relu(conv3(t2) + identity) and the NEXT bottleneck's relu(conv1(.)) in one launch
+    (resnet.py:146-154 + 137-139) == the two hands_conv2d_nhwc_f32 launches, bit for bit, and right against fp64."""
+    L = _lib.lib()
+    H = 8 if B == 2 else 56                      # M = B * H * H: 128 pixels (2 tiles) / 116 032 (more tiles than workgroups)
+    g = torch.Generator().manual_seed(C1 + B)
+    w3 = torch.randn(256, 64, 1, 1, generator=g) / 8
+    w1 = torch.randn(C1, 256, 1, 1, generator=g) / 16
+    c3 = pack_conv(w3, torch.randn(256, generator=g), 1, 0, DEV)
+    c1 = pack_conv(w1, torch.randn(C1, generator=g), 1, 0, DEV)
+    t2 = torch.randn(B, H, H, 64, generator=g).to(DEV)
+    ident = torch.randn(B, H, H, 256, generator=g).to(DEV)
+    eng = ConvEngine()
+    M = B * H * H
+    assert eng.link_ok(c3, c1, M)
+    out_a, t1_a = torch.full((M, 256), float("nan"), device=DEV), torch.full((M, C1), float("nan"), device=DEV)
+    eng.conv(L, c3, t2, B, H, H, out_a, True, _stream(), res=ident)
+    eng.conv(L, c1, out_a, B, H, H, t1_a, True, _stream())
+    out_b, t1_b = torch.full((M, 256), float("nan"), device=DEV), torch.full((M, C1), float("nan"), device=DEV)
+    eng.bottleneck_link(L, c3, c1, t2, ident, out_b, t1_b, M, _stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b) and torch.equal(t1_a, t1_b)
+    x64 = t2.cpu().double().view(M, 64)
+    o64 = F.relu(x64 @ w3.double().view(256, 64).T + c3.bias[:256].cpu().double() + ident.cpu().double().view(M, 256))
+    t64 = F.relu(o64 @ w1.double().view(C1, 256).T + c1.bias[:C1].cpu().double())
+    assert (out_b.cpu().double() - o64).abs().max().item() < 2e-5 * max(1.0, o64.abs().max().item())
+    assert (t1_b.cpu().double() - t64).abs().max().item() < 2e-5 * max(1.0, t64.abs().max().item())
+    # refused shapes fall back to the two launches in the model (engine.link_ok): the entry point itself says EINVAL
+    assert L.hands_bottleneck_link_f32(ptr(t2), ptr(c3.w), ptr(c3.bias), ptr(ident), ptr(out_b), ptr(c1.w), ptr(c1.bias),
+                                       ptr(t1_b), M - 1, C1, _stream()) != 0
+
+
+def test_forward_with_and_without_the_fused_seam_is_bit_identical(gpu_model):
+    inputs, meta_info = synthetic_inputs(3, 9, device=DEV)
+    a = {k: v.clone() for k, v in gpu_model(inputs, meta_info).items()}
+    gpu_model.engine.fuse_link = True            # opt-in (measured slower than the separate launches: engine.py)
+    try:
+        b = {k: v.clone() for k, v in gpu_model(inputs, meta_info).items()}
+    finally:
+        gpu_model.engine.fuse_link = False
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
