@@ -397,6 +397,10 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
   const int e12 = lane & 15;                         // MFMA row of the transform GEMM: entry e of A_u (12 used)
 
   for (int ch = c0; ch < c1; ++ch) {
+#if defined(HANDS_MANO_ABL) && HANDS_MANO_ABL == 3      // timing-only ablation: no blend product
+    for (int e = tid; e < MH * VROW; e += 256) (&stage[0][0])[e] = 1.f;
+    __syncthreads();
+#else
     // -- blend GEMM of this chunk: wave w owns row tiles w, w+4, w+8.  A weight fragment (16 rows x 4 k per
     //    instruction, straight from L2 in operand order) feeds one MFMA per 16-hand group, so the 1.5 MB blend
     //    matrix is streamed once per MH hands; the groups' accumulation chains are independent and interleaved
@@ -445,6 +449,8 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
       }
     }
     __syncthreads();
+#endif
+#if !(defined(HANDS_MANO_ABL) && HANDS_MANO_ABL == 2)   // timing-only ablation 2: no skinning product
     // -- skinning: T[v][h] = sum_u w[v][u] A_h[u] as a (12 x 16 joints) x (16 joints x 16 vertices) product per hand
     //    on the matrix cores; lane (vertex, g < 3) then holds row g of T and applies it to the posed vertex
     const int vl = wave * 16 + (lane & 15);
@@ -483,6 +489,10 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
         }
       }
     }
+#else
+    const int vl = wave * 16 + (lane & 15);
+#endif
+#if !(defined(HANDS_MANO_ABL) && HANDS_MANO_ABL == 4)   // timing-only ablation 4: no vertex write-back
     // the wave's 16 vertices x 3 coordinates of every hand are 48 consecutive floats both in the stage and in
     // the output arrays: write them back 8 bytes per lane (hand rows are 9336 B apart: 8-byte aligned)
 #pragma unroll
@@ -499,6 +509,7 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
             make_float2(o2.x + sCam[h][c0i], o2.y + sCam[h][c1i]);
       }
     }
+#endif
     __syncthreads();      // the stage is rewritten by the next chunk's GEMM
   }
   // ---- fingertip joints 16..20 of the tips whose vertex this block skinned: joints3d, camera space, projection

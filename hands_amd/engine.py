@@ -49,10 +49,16 @@ class ConvEngine:
         self._splitk_ws = {}          # (device, stream handle) -> workspace tensor
         self._sk_ws = {}              # (device, stream handle) -> [zeroed stream-K workspace, epoch counter]
         self._capture_ws = {}         # split-K workspaces of launches recorded into a hipGraph (graph memory pool)
+        self.fuse_splitk_reduce = False  # split-K as ONE launch: the last slice of a tile to arrive reduces it (per-tile
+                                         # arrival counters; fixed slice order -> same bits as the two-pass form).  Built,
+                                         # tested bit-identical, measured SLOWER (round 3: handoccnet_light at 32/GPU -3.5 %,
+                                         # hands_light serial +0.7 ms): every workgroup pays an agent-scope release (L2
+                                         # write-back) that the kernel boundary of the two-pass form gives for free.  Opt-in.
+        self._splitk_counters = {}    # (device, stream handle[, "capture"]) -> zeroed int32 counters, self-resetting
 
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
-        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "fuse_mano", "fuse_link", "stream_k", "math"):
+        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "fuse_mano", "fuse_link", "fuse_splitk_reduce", "stream_k", "math"):
             setattr(e, k, getattr(self, k))
         return e
 
@@ -61,7 +67,7 @@ class ConvEngine:
         stream handle the launch went to: a model calls this when it drops its side streams (``invalidate_packed``,
         ``.to()``), so a later stream that happens to get a recycled handle starts from a fresh, zero-filled
         workspace and no destroyed stream keeps 64 MB pinned."""
-        for table in (self._splitk_ws, self._sk_ws, self._capture_ws):
+        for table in (self._splitk_ws, self._sk_ws, self._capture_ws, self._splitk_counters):
             for key in [k for k in table if dev is None or k[0] == dev]:
                 del table[key]
 
@@ -89,6 +95,16 @@ class ConvEngine:
                 torch.cuda.synchronize(dev)
             ws = table[key] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=dev)
         return ws
+
+    def _counters(self, L, dev, stream):
+        """Per-tile arrival counters of the one-launch split-K (zero between launches; one set per stream)."""
+        key = (dev, stream, self._capturing(L, stream))
+        c = self._splitk_counters.get(key)
+        if c is None:
+            c = self._splitk_counters[key] = torch.zeros(8192, dtype=torch.int32, device=dev)
+            if not key[2]:
+                torch.cuda.current_stream(dev).synchronize()      # zero-fill done before a side stream uses it
+        return c
 
     def conv(self, L, pc, x, B, H, W, out, relu, stream, res=None, in_ps=None, out_ps=None, res_ps=None,
              x_off=0, out_off=0, res_off=0, splitk=False, splitk_n=0):
@@ -121,8 +137,10 @@ class ConvEngine:
             hook("begin", pc, B * Ho * Wo, stream, res is not None, kname)
         if S > 1:     # latency-bound GEMM: deterministic split-K with a per-stream workspace
             ws = self._workspace(L, x.device, stream, L.hands_conv2d_workspace_floats(C.byref(d), S))
-            check(L.hands_conv2d_nhwc_splitk_n_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias), rp, ptr(out, out_off),
-                                                   S, ptr(ws), ws.numel(), stream), "hands_conv2d_nhwc_splitk_n_f32")
+            cnt = self._counters(L, x.device, stream) if self.fuse_splitk_reduce else None
+            check(L.hands_conv2d_nhwc_splitk_fused_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias), rp, ptr(out, out_off),
+                                                       S, ptr(ws), ws.numel(), ptr(cnt), cnt.numel() if cnt is not None else 0,
+                                                       stream), "hands_conv2d_nhwc_splitk_fused_f32")
         elif use_sk:
             key = (x.device, stream)
             sk = self._sk_ws.get(key)

@@ -113,6 +113,15 @@ int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const float* in, co
                                    const float* bias, const float* residual, float* out, int S,
                                    float* workspace, long long workspace_floats, hands_stream_t stream);
 
+/* The same split-K as ONE launch: `counters` (>= one int per output tile of the launch: ceil(M/128)*ceil(Cout/128), or
+ * ceil(M/256) for Cout <= 64; zero before the first use, left zero by every launch) lets the LAST slice of a tile to
+ * arrive add the S partial tiles in ascending slice order and apply bias / residual / activation -- exactly the
+ * arithmetic of the two-pass form, so the output bits are identical and independent of the arrival order.  A workspace
+ * and its counters belong to one stream at a time.  counters == NULL or too few: the two-pass form. */
+int hands_conv2d_nhwc_splitk_fused_f32(const hands_conv_desc* desc, const float* in, const float* w_packed,
+                                       const float* bias, const float* residual, float* out, int S, float* workspace,
+                                       long long workspace_floats, int* counters, int n_counters, hands_stream_t stream);
+
 /* Stream-K form of hands_conv2d_nhwc_f32 for launches whose tile count quantises badly on the chip (400-1600
  * tiles on 256 CUs leave 12-24 % of it idle): G persistent workgroups take equal shares of the (tile, k-step)
  * units; a tile cut between two workgroups is finished by the second one CONTINUING the first one's fp32 FMA chain

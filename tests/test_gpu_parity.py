@@ -950,3 +950,48 @@ def test_forward_with_and_without_the_fused_seam_is_bit_identical(gpu_model):
         gpu_model.engine.fuse_link = False
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+SPLITK_FUSED_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, act, residual, S
+    (64, 128, 8, 8, 128, 3, 1, 1, 3, False, 4),      # handoccnet hourglass level (LeakyReLU), 32 tiles x 4 slices
+    (64, 256, 4, 4, 128, 1, 1, 0, 3, True, 2),       # pointwise + residual
+    (256, 2304, 1, 1, 2048, 1, 1, 0, 1, False, 8),   # feature_conv's Linear: 2 x 16 tiles x 8 slices
+    (700, 1024, 1, 1, 112, 1, 1, 0, 0, True, 4),     # HMR decoders (N tail: 112 of 128), ragged M, in-place style residual
+    (37, 64, 9, 11, 20, 3, 2, 1, 2, False, 3),       # narrow tile, GELU, ragged everything
+    (512, 512, 7, 7, 512, 3, 1, 1, 1, False, 2),     # 784 tiles x 2 slices: several workgroups resident per CU
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_FUSED_CASES)
+def test_splitk_reduce_in_the_launch_is_bit_identical(case):
+    """hands_conv2d_nhwc_splitk_fused_f32 (the last slice of a tile to arrive reduces it) == the two-pass
+    hands_conv2d_nhwc_splitk_n_f32 bit for bit -- the additions run in slice order, never in arrival order --, is
+    reproducible over repeated launches and leaves its counters zero."""
+    B, Cin, H, W, Cout, k, stride, pad, act, use_res, S = case
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(sum(case))
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    pc = pack_conv(w, torch.randn(Cout, generator=g), stride, pad, DEV)
+    x = torch.randn(B, H, W, Cin, generator=g).to(DEV)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Ho, Wo, pc.Cout, generator=g).to(DEV) if use_res else None
+    outs = {}
+    for fused in (False, True, True):
+        eng = ConvEngine()
+        eng.fuse_splitk_reduce = fused
+        out = torch.full((B, Ho, Wo, pc.Cout), float("nan"), device=DEV)
+        for _ in range(3 if fused else 1):
+            eng.conv(L, pc, x, B, H, W, out, act, _stream(), res=res, splitk_n=S)
+        torch.cuda.synchronize()
+        if fused:
+            cnt = next(iter(eng._splitk_counters.values()))
+            assert int(cnt.abs().sum().item()) == 0
+            assert torch.equal(out, outs[False])
+        outs[fused] = out.clone()
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double(), pc.bias[:Cout].double().cpu(), stride=stride, padding=pad)
+    if res is not None:
+        ref = ref + res.permute(0, 3, 1, 2)[:, :Cout].double().cpu()
+    ref = {0: ref, 1: F.relu(ref), 2: F.gelu(ref), 3: F.leaky_relu(ref, 0.01)}[act]
+    got = outs[True].permute(0, 3, 1, 2)[:, :Cout].double().cpu()
+    assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
