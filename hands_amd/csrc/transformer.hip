@@ -12,6 +12,16 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// exp(x) for finite x <= 0: exp2 of a compensated x * log2(e) (v_exp_f32 on [-0.5, 0.5] + v_ldexp_f32, ~1 ulp; the
+// library's expf carries range checks that cannot trigger here)
+__device__ __forceinline__ float exp_nonpos(float x) {
+  const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;
+  const float n = rintf(x * L2E_HI);
+  float f = fmaf(x, L2E_HI, -n);
+  f = fmaf(x, L2E_LO, f);
+  return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
 __device__ __forceinline__ float f4e(const float4& v, int t) {
   return t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w));
 }
@@ -140,7 +150,7 @@ __global__ void kpe_encode_kernel(const float* __restrict__ center, const float*
 // where MFMA step r of key block kb contracts the key pair {(r&3)+8(r>>2), +4} -- exactly the keys the
 // two half-waves hold in accumulator register r.  K and V^T are staged in LDS one after the other.
 template <int TB, int D>
-__global__ void __launch_bounds__(64 * TB) attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+__global__ void __launch_bounds__(64 * TB) __attribute__((amdgpu_waves_per_eu(3, 3))) attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                             int heads, float scale) {
   constexpr int T = 32 * TB;
   constexpr int KR = D + 4;          // K row (floats): (D+4)*4 B is an odd number of 16-B slots for D = 80
@@ -201,7 +211,8 @@ __global__ void __launch_bounds__(64 * TB) attention_kernel(const float* __restr
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(kf, t), f4e(qf[kk], t), s[kb], 0, 0, 0);
     }
   }
-  // softmax over the keys of this lane's query: exp(x - max) / sum
+  // softmax over the keys of this lane's query: exp(x - max) * (1 / sum): one reciprocal per query instead of 96
+  // divisions (~10 instructions each); e * (1 / sum) vs e / sum differ by the last rounding only
   float m = s[0][0];
 #pragma unroll
   for (int kb = 0; kb < TB; ++kb)
@@ -212,22 +223,35 @@ __global__ void __launch_bounds__(64 * TB) attention_kernel(const float* __restr
 #pragma unroll
   for (int kb = 0; kb < TB; ++kb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[kb][r] = expf(s[kb][r] - m); sum += s[kb][r]; }
+    for (int r = 0; r < 16; ++r) { s[kb][r] = exp_nonpos(s[kb][r] - m); sum += s[kb][r]; }
   sum += __shfl_xor(sum, 32);
+  const float inv_sum = 1.0f / sum;
 #pragma unroll
   for (int kb = 0; kb < TB; ++kb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[kb][r] = s[kb][r] / sum;
+    for (int r = 0; r < 16; ++r) s[kb][r] *= inv_sum;
 
   __syncthreads();   // every wave is done with K
-  // V^T -> LDS: lanes walk tokens, so the transposed scalar writes are conflict-free
-  for (int i = tid; i < T * (D / 4); i += NT) {
-    const int t = i % T, dq = i / T;
-    const float4 v = *reinterpret_cast<const float4*>(base + (long long)t * 3 * C + 2 * C + dq * 4);
-    lds[(dq * 4 + 0) * VR + t] = v.x;
-    lds[(dq * 4 + 1) * VR + t] = v.y;
-    lds[(dq * 4 + 2) * VR + t] = v.z;
-    lds[(dq * 4 + 3) * VR + t] = v.w;
+  __builtin_amdgcn_sched_barrier(0);      // keep the 10 loads below the softmax: hoisted, they cost the third wave per SIMD
+  // V^T -> LDS: lanes walk tokens, so the transposed scalar writes are conflict-free; all loads of a thread in flight
+  // before its first LDS store
+  {
+    float4 vv[FILL];
+#pragma unroll
+    for (int it = 0; it < FILL; ++it) {
+      const int i = tid + it * NT;
+      const int t = i % T, dq = i / T;
+      vv[it] = *reinterpret_cast<const float4*>(base + (long long)t * 3 * C + 2 * C + dq * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < FILL; ++it) {
+      const int i = tid + it * NT;
+      const int t = i % T, dq = i / T;
+      lds[(dq * 4 + 0) * VR + t] = vv[it].x;
+      lds[(dq * 4 + 1) * VR + t] = vv[it].y;
+      lds[(dq * 4 + 2) * VR + t] = vv[it].z;
+      lds[(dq * 4 + 3) * VR + t] = vv[it].w;
+    }
   }
   __syncthreads();
 
