@@ -501,6 +501,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
   const int n_lane = n0 + wn * 64 + c4 * 4;
   const bool n_ok = n_lane < a.N;
   const bool part = a.ksplit > 1;                   // split-K: raw partial sums, reduced by splitk_reduce_kernel
+#ifdef HANDS_ABL_NO_EPI      // timing-only ablation (tools/build_variant.sh): no epilogue at all (one impossible store keeps the MFMAs)
+  if (!part && m0 + BM <= a.M && n0 + BN <= a.N) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) sacc += acc[i][j][0] + acc[i][j][7] + acc[i][j][15];
+    if (sacc == 123456.789f) a.out[(size_t)m0 * a.out_ps + n0 + lane] = sacc;
+    return;
+  }
+#endif
   if (!part && m0 + BM <= a.M && n0 + BN <= a.N) {      // (uniform) full tile: straight-line epilogue, activation compiled in
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int mw = m0 + (wave_u / WAVES_N) * 64, nw = n0 + (wave_u % WAVES_N) * 64;
