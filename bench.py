@@ -286,6 +286,8 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         model.async_tail = os.environ["HANDS_ASYNC_TAIL"] == "1"
     if os.environ.get("HANDS_SMALL_MAP_SPLITK") and hasattr(model, "small_map_splitk"):      # developer A/B switch
         model.small_map_splitk = os.environ["HANDS_SMALL_MAP_SPLITK"] == "1"
+    if os.environ.get("HANDS_FUSE_PRE"):           # developer A/B switch
+        model.engine.fuse_pre = os.environ["HANDS_FUSE_PRE"] == "1"
     if os.environ.get("HANDS_FUSE_SPLITK"):        # developer A/B switch
         model.engine.fuse_splitk_reduce = os.environ["HANDS_FUSE_SPLITK"] == "1"
     if os.environ.get("HANDS_FUSE_LINK"):          # developer A/B switch

@@ -64,6 +64,7 @@ SIGNATURES = {
     "hands_conv2d_nhwc_streamk_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_longlong, _I, _P],
     "hands_conv1x1_dual_nhwc_f32": [C.POINTER(ConvDesc), _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "hands_conv2d_nhwc_splitk_n_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P, C.c_longlong, _P],
+    "hands_conv2d_nhwc_pre_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _I, _P, C.c_longlong, _P],
     "hands_conv2d_nhwc_splitk_fused_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P, C.c_longlong, _P, _I, _P],
     "hands_stem_conv_maxpool_nhwc_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hands_stem_conv_maxpool_nchw_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -96,6 +96,11 @@ struct ConvArgs {
   int* counters;
   const float* fin_res;
   int fin_res_ps, fin_act;
+  // PRE instantiations (pointwise layers): the activation operand is leaky_relu(x * pre_scale[k] + pre_shift[k], 0.01) --
+  // the eval BatchNorm -> LeakyReLU that PRECEDES the first convolution of a pre-activation residual unit
+  // (handoccnet_light/hand_head.py:131-133,170-172), applied on the way into LDS instead of by a launch of its own
+  const float* pre_scale;
+  const float* pre_shift;
 };
 
 // XCD-aware block remap: blocks are dispatched round-robin over the 8 XCDs (private L2 each);
@@ -186,7 +191,7 @@ constexpr int SK_SLOT_FLOATS = 4 * 64 * 64;   // one workgroup's accumulators: 4
 // both operands are split on the way into LDS into three bf16 planes whose sum is the fp32 value exactly, and a
 // k-16 step is six v_mfma_f32_32x32x16_bf16 (the products b_i * b_j with i + j <= 2, fp32 accumulation): the
 // dropped terms are <= 2^-24 of a product -- fp32-grade results at 3/8 of the matrix-pipe time.
-template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool FIN = false>
+template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool FIN = false, bool PRE = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int tile, int split, int kt0, int kt1,
                                           const float* acc_in, float* acc_out) {
   constexpr int ROW = PREC ? LDS_ROW_B3 : LDS_ROW;
@@ -305,6 +310,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
 
   // staging registers (explicit scalars-of-float4: arrays captured by lambdas ended up in scratch)
   float4 xr[A_ROWS], wr[W_ROWS];
+  static_assert(!PRE || (MODE == 2 && PREC == 0), "the input affine + LeakyReLU exists for exact-fp32 pointwise layers");
+  float4 psr = make_float4(1.f, 1.f, 1.f, 1.f), pbr = make_float4(0.f, 0.f, 0.f, 0.f);   // PRE: scale / shift of the staged k chunk
   // k-step state (wave-uniform for the regular path)
   int kh = 0, kw = 0, c0 = 0, woff = 0;
   const int ntaps = a.KH * a.KW;
@@ -355,6 +362,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
       }                                                                                             \
     }                                                                                               \
     if constexpr (MODE != 0) woff = (KT) * BK;                                                      \
+    if constexpr (PRE) {                                                                            \
+      psr = *reinterpret_cast<const float4*>(a.pre_scale + (KT) * BK + chunk * 4);                  \
+      pbr = *reinterpret_cast<const float4*>(a.pre_shift + (KT) * BK + chunk * 4);                  \
+    }                                                                                               \
     _Pragma("unroll") for (int i = 0; i < W_ROWS; ++i) {                                            \
       const u32x4 ld = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_offb[i], woff * 4, 0);        \
       wr[i] = make_float4(__uint_as_float(ld.x), __uint_as_float(ld.y), __uint_as_float(ld.z), __uint_as_float(ld.w)); \
@@ -363,6 +374,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
 
 #define STORE_TILES(BUF)                                                                            \
   do {                                                                                              \
+    if constexpr (PRE) {                                                                            \
+      _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i) {                                          \
+        float4 v = make_float4(xr[i].x * psr.x + pbr.x, xr[i].y * psr.y + pbr.y, xr[i].z * psr.z + pbr.z, xr[i].w * psr.w + pbr.w); \
+        v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;                   \
+        v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;                   \
+        xr[i] = v;                                                                                  \
+      }                                                                                             \
+    }                                                                                               \
     if constexpr (PREC == 0) {                                                                      \
       float* dx = sX + (BUF) * BM * ROW + srow * ROW + swz_chunk * 4;                               \
       float* dw = sW + (BUF) * BN * ROW + srow * ROW + swz_chunk * 4;                               \
@@ -609,7 +628,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
 #undef STORE_TILES
 }
 
-template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool FIN = false>
+template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool FIN = false, bool PRE = false>
 __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   constexpr int RING = 2 * (64 * WAVES_M + 64 * WAVES_N) * (PREC ? LDS_ROW_B3 : LDS_ROW);
   __shared__ __attribute__((aligned(16))) float lds[RING > EPI_FLOATS ? RING : EPI_FLOATS];
@@ -620,7 +639,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   const int nk_all = a.Kpad / BK;
   const int kt0 = a.ksplit > 1 ? (int)((long long)split * nk_all / a.ksplit) : 0;
   const int kt1 = a.ksplit > 1 ? (int)((long long)(split + 1) * nk_all / a.ksplit) : nk_all;
-  conv_tile<WAVES_M, WAVES_N, MODE, PREC, FIN>(a, lds, tile, split, kt0, kt1, nullptr, nullptr);
+  conv_tile<WAVES_M, WAVES_N, MODE, PREC, FIN, PRE>(a, lds, tile, split, kt0, kt1, nullptr, nullptr);
 }
 
 // ---- stream-K: persistent workgroups with equal shares of (tile, k-step) units -------------------------------
@@ -705,14 +724,14 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sk_f32_kernel(ConvArgs a, S
   }
 }
 
-template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool FIN = false>
+template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool FIN = false, bool PRE = false>
 int launch(ConvArgs& a, hipStream_t stream) {
   constexpr int BM = 64 * WAVES_M, BN = 64 * WAVES_N;
   a.nblk_m = (a.M + BM - 1) / BM;
   a.nblk_n = (a.N + BN - 1) / BN;
   const long long nwg = (long long)a.nblk_m * a.nblk_n * (a.ksplit > 1 ? a.ksplit : 1);
   if (nwg <= 0 || nwg > 0x7fffffffLL) return HANDS_EINVAL;
-  hipLaunchKernelGGL((conv_igemm_f32_kernel<WAVES_M, WAVES_N, MODE, PREC, FIN>), dim3((unsigned)nwg), dim3(256), 0,
+  hipLaunchKernelGGL((conv_igemm_f32_kernel<WAVES_M, WAVES_N, MODE, PREC, FIN, PRE>), dim3((unsigned)nwg), dim3(256), 0,
                      stream, a);
   return (int)hipGetLastError();
 }
@@ -878,7 +897,7 @@ extern "C" int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, 
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
   a.relu = d->act & HANDS_ACT_MASK;
-  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.counters = nullptr; a.fin_res = nullptr; a.fin_res_ps = 0; a.fin_act = 0;
+  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.counters = nullptr; a.fin_res = nullptr; a.fin_res_ps = 0; a.fin_act = 0; a.pre_scale = nullptr; a.pre_shift = nullptr;
   a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
   hipStream_t s = (hipStream_t)stream;
   if (stem) return (d->Cout <= 64) ? launch<4, 1, 1>(a, s) : launch<2, 2, 1>(a, s);
@@ -918,7 +937,7 @@ extern "C" int hands_conv2d_nhwc_streamk_f32(const hands_conv_desc* d, const flo
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
   if (d->act & HANDS_MATH_BF16X3) return hands_conv2d_nhwc_f32(d, in, w_packed, bias, residual, out, stream);
   a.relu = d->act & HANDS_ACT_MASK;
-  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.counters = nullptr; a.fin_res = nullptr; a.fin_res_ps = 0; a.fin_act = 0;
+  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.counters = nullptr; a.fin_res = nullptr; a.fin_res_ps = 0; a.fin_act = 0; a.pre_scale = nullptr; a.pre_shift = nullptr;
   a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
   hipStream_t s = (hipStream_t)stream;
   if (pointwise_route_ok(d))
@@ -953,7 +972,7 @@ extern "C" int hands_conv1x1_dual_nhwc_f32(const hands_conv_desc* d, const float
   a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0;
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = 0;
   a.relu = d->act & HANDS_ACT_MASK;
-  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.counters = nullptr; a.fin_res = nullptr; a.fin_res_ps = 0; a.fin_act = 0;
+  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.counters = nullptr; a.fin_res = nullptr; a.fin_res_ps = 0; a.fin_act = 0; a.pre_scale = nullptr; a.pre_shift = nullptr;
   a.in2 = in2; a.K0 = d->Cin; a.H2 = H2; a.W2 = W2; a.stride2 = stride2; a.in2_ps = in2_pix_stride;
   hipStream_t s = (hipStream_t)stream;
   if (d->act & HANDS_MATH_BF16X3) return (d->Cout <= 64) ? launch<4, 1, 2, 1>(a, s) : launch<2, 2, 2, 1>(a, s);
@@ -961,18 +980,25 @@ extern "C" int hands_conv1x1_dual_nhwc_f32(const hands_conv_desc* d, const float
 }
 
 namespace {
+int pre_launch(const hands_conv_desc* d, const float* in, const float* pre_scale, const float* pre_shift,
+               const float* w_packed, const float* bias, const float* residual, float* out, hands_stream_t stream);
+
 int splitk_launch(const hands_conv_desc* d, const float* in, const float* w_packed, const float* bias, const float* residual,
                   float* out, int S, float* workspace, long long workspace_floats, int* counters, int n_counters,
-                  hands_stream_t stream) {
+                  hands_stream_t stream, const float* pre_scale = nullptr, const float* pre_shift = nullptr) {
   if (!d) return HANDS_EINVAL;
+  const bool pre = pre_scale != nullptr;
+  if (pre && (!pre_shift || !pointwise_route_ok(d) || (d->act & HANDS_MATH_BF16X3))) return HANDS_EINVAL;
   const long long M = (long long)d->B * d->Ho * d->Wo;
   const int part_ps = d->Cout;                          // Cout % 4 == 0
   if (S > d->Kpad / BK) S = d->Kpad / BK;
   if (S <= 1 || !workspace || workspace_floats < (long long)S * M * part_ps)
-    return hands_conv2d_nhwc_f32(d, in, w_packed, bias, residual, out, stream);
+    return pre ? pre_launch(d, in, pre_scale, pre_shift, w_packed, bias, residual, out, stream)
+               : hands_conv2d_nhwc_f32(d, in, w_packed, bias, residual, out, stream);
   if (!in || !w_packed || !bias || !out || !conv_geometry_ok(d) || S > 64) return HANDS_EINVAL;
   const bool stem = d->Cin == 4;
   ConvArgs a;
+  a.pre_scale = pre_scale; a.pre_shift = pre_shift;
   a.in = in; a.w = w_packed; a.bias = bias; a.res = nullptr; a.out = out;
   a.M = (int)M; a.N = d->Cout; a.Kpad = d->Kpad;
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
@@ -984,12 +1010,13 @@ int splitk_launch(const hands_conv_desc* d, const float* in, const float* w_pack
   // one launch: the last slice of a tile to arrive reduces it (needs one zeroed, self-resetting counter per tile)
   const bool narrow = d->Cout <= 64;
   const long long ntiles = narrow ? ((M + 255) / 256) * ((d->Cout + 63) / 64) : ((M + 127) / 128) * ((d->Cout + 127) / 128);
-  const bool fused = counters != nullptr && ntiles <= n_counters && !stem;
+  const bool fused = counters != nullptr && ntiles <= n_counters && !stem && !pre;
   a.counters = fused ? counters : nullptr;
   a.fin_res = residual; a.fin_res_ps = d->res_pix_stride; a.fin_act = d->act & HANDS_ACT_MASK;
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (stem) rc = (d->Cout <= 64) ? launch<4, 1, 1>(a, s) : launch<2, 2, 1>(a, s);
+  if (pre) rc = (d->Cout <= 64) ? launch<4, 1, 2, 0, false, true>(a, s) : launch<2, 2, 2, 0, false, true>(a, s);
+  else if (stem) rc = (d->Cout <= 64) ? launch<4, 1, 1>(a, s) : launch<2, 2, 1>(a, s);
   else if (fused && pointwise_route_ok(d)) rc = (d->Cout <= 64) ? launch<4, 1, 2, 0, true>(a, s) : launch<2, 2, 2, 0, true>(a, s);
   else if (fused) rc = (d->Cout <= 64) ? launch<4, 1, 0, 0, true>(a, s) : launch<2, 2, 0, 0, true>(a, s);
   else if (pointwise_route_ok(d)) rc = (d->Cout <= 64) ? launch<4, 1, 2>(a, s) : launch<2, 2, 2>(a, s);
@@ -1000,7 +1027,33 @@ int splitk_launch(const hands_conv_desc* d, const float* in, const float* w_pack
                      d->Cout / 4, part_ps, bias, residual, d->res_pix_stride, out, d->out_pix_stride, d->act & HANDS_ACT_MASK);
   return (int)hipGetLastError();
 }
+int pre_launch(const hands_conv_desc* d, const float* in, const float* pre_scale, const float* pre_shift,
+               const float* w_packed, const float* bias, const float* residual, float* out, hands_stream_t stream) {
+  if (!d || !in || !pre_scale || !pre_shift || !w_packed || !bias || !out) return HANDS_EINVAL;
+  if (!conv_geometry_ok(d) || !pointwise_route_ok(d) || (d->act & HANDS_MATH_BF16X3)) return HANDS_EINVAL;
+  ConvArgs a;
+  a.in = in; a.w = w_packed; a.bias = bias; a.res = residual; a.out = out;
+  a.M = d->B * d->Ho * d->Wo; a.N = d->Cout; a.Kpad = d->Kpad;
+  a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+  a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
+  a.relu = d->act & HANDS_ACT_MASK;
+  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.counters = nullptr; a.fin_res = nullptr; a.fin_res_ps = 0; a.fin_act = 0;
+  a.pre_scale = pre_scale; a.pre_shift = pre_shift;
+  a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
+  hipStream_t s = (hipStream_t)stream;
+  return (d->Cout <= 64) ? launch<4, 1, 2, 0, false, true>(a, s) : launch<2, 2, 2, 0, false, true>(a, s);
+}
 }  // namespace
+
+extern "C" int hands_conv2d_nhwc_pre_f32(const hands_conv_desc* d, const float* in, const float* pre_scale,
+                                         const float* pre_shift, const float* w_packed, const float* bias,
+                                         const float* residual, float* out, int S, float* workspace,
+                                         long long workspace_floats, hands_stream_t stream) {
+  if (S > 1) return splitk_launch(d, in, w_packed, bias, residual, out, S, workspace, workspace_floats, nullptr, 0, stream,
+                                  pre_scale, pre_shift);
+  return pre_launch(d, in, pre_scale, pre_shift, w_packed, bias, residual, out, stream);
+}
 
 extern "C" int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
                                               const float* bias, const float* residual, float* out, int S,

@@ -36,6 +36,8 @@ class ConvEngine:
                                       # reported mode: operands split into three exact bf16 planes, six bf16 MFMAs per
                                       # k-16 step with fp32 accumulation (HANDS_MATH_BF16X3); never the headline
         self.fuse_mano = True         # MANOHead.forward of both hands as one launch (hands_mano_heads_f32)
+        self.fuse_pre = True          # handoccnet_light's pre-activation units: BatchNorm -> LeakyReLU folded into the operand
+                                      # staging of the unit's first (pointwise) convolution (hands_conv2d_nhwc_pre_f32)
         self.fuse_link = False        # layer1: conv3 + identity + ReLU of block i and conv1 + ReLU of block i + 1 as one
                                       # launch (hands_bottleneck_link_f32): `out` is not re-read from HBM; bit-identical.
                                       # Built and measured (profiles/README.md, round 3): its 64-pixel x 256-channel LDS tile
@@ -58,7 +60,7 @@ class ConvEngine:
 
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
-        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "fuse_mano", "fuse_link", "fuse_splitk_reduce", "stream_k", "math"):
+        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "fuse_mano", "fuse_pre", "fuse_link", "fuse_splitk_reduce", "stream_k", "math"):
             setattr(e, k, getattr(self, k))
         return e
 
@@ -107,7 +109,7 @@ class ConvEngine:
         return c
 
     def conv(self, L, pc, x, B, H, W, out, relu, stream, res=None, in_ps=None, out_ps=None, res_ps=None,
-             x_off=0, out_off=0, res_off=0, splitk=False, splitk_n=0):
+             x_off=0, out_off=0, res_off=0, splitk=False, splitk_n=0, pre=None):
         """One convolution / linear layer.  ``splitk=True`` marks rows that are per-SAMPLE (head MLPs): only
         there may the library cut K by its own (layer-only) policy -- token / pixel GEMMs would cross the
         library's row threshold between batch sizes and lose bit-reproducibility.  ``splitk_n`` is a
@@ -129,6 +131,19 @@ class ConvEngine:
             tiles = -(-(B * Ho * Wo) // bm) * -(-pc.Cout // bn)
             S = max(S, min(256 // tiles, pc.Kpad // 128, 32)) if tiles <= 128 else S
         rp = ptr(res, res_off) if res is not None else None
+        if pre is not None:
+            # pointwise layer behind an eval BatchNorm -> LeakyReLU (pre = (scale, shift) device vectors): the affine +
+            # activation is applied to the operand on its way into LDS (hands_conv2d_nhwc_pre_f32)
+            kname = "conv_igemm_splitk_f32_kernel" if S > 1 else "conv_igemm_f32_kernel"
+            if hook is not None:
+                hook("begin", pc, B * Ho * Wo, stream, res is not None, kname)
+            ws = self._workspace(L, x.device, stream, L.hands_conv2d_workspace_floats(C.byref(d), S)) if S > 1 else None
+            check(L.hands_conv2d_nhwc_pre_f32(C.byref(d), ptr(x, x_off), ptr(pre[0]), ptr(pre[1]), ptr(pc.w), ptr(pc.bias), rp,
+                                              ptr(out, out_off), S, ptr(ws), ws.numel() if ws is not None else 0, stream),
+                  "hands_conv2d_nhwc_pre_f32")
+            if hook is not None:
+                hook("end", pc, B * Ho * Wo, stream, res is not None, kname)
+            return Ho, Wo
         use_sk = S <= 1 and self.math == "fp32" and ((not self.overlap) if self.stream_k == "auto" else self.stream_k) and \
             L.hands_conv2d_streamk_grid(C.byref(d)) > 0 and not self._capturing(L, stream)
         # (not under hipGraph capture: the zero-filled workspace of a new stream cannot be set up inside one)

@@ -370,9 +370,13 @@ class HandOccNet(EngineSwitches, nn.Module):
             # -- regressor (hand_head.py, mano_head.py:190-207) -------------------------------------------
             def unit(u, x, H, W):
                 n = B2 * H * W
-                t0 = new(n, CF)
-                check(L.hands_bn_leaky_f32(ptr(x), ptr(u["pre"][0]), ptr(u["pre"][1]), ptr(t0), n, CF, stream), "bn_leaky")
-                t1 = conv(u["c1"], t0, B2, H, W, ACT_LEAKY_RELU)[0]
+                if self.engine.fuse_pre and self.engine.math == "fp32":
+                    # BatchNorm -> LeakyReLU of the pre-activation unit applied to conv1's operand on its way into LDS
+                    t1 = conv(u["c1"], x, B2, H, W, ACT_LEAKY_RELU, pre=u["pre"])[0]
+                else:
+                    t0 = new(n, CF)
+                    check(L.hands_bn_leaky_f32(ptr(x), ptr(u["pre"][0]), ptr(u["pre"][1]), ptr(t0), n, CF, stream), "bn_leaky")
+                    t1 = conv(u["c1"], t0, B2, H, W, ACT_LEAKY_RELU)[0]
                 t2 = conv(u["c2"], t1, B2, H, W, ACT_LEAKY_RELU)[0]
                 return conv(u["c3"], t2, B2, H, W, res=x)[0]
 

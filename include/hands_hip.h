@@ -113,6 +113,17 @@ int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const float* in, co
                                    const float* bias, const float* residual, float* out, int S,
                                    float* workspace, long long workspace_floats, hands_stream_t stream);
 
+/* Pointwise layer (1x1, no padding) whose INPUT first goes through a per-channel affine + LeakyReLU(0.01):
+ *     out = act( bias + W . leaky_relu(in * pre_scale[c] + pre_shift[c]) (+ residual) )
+ * i.e. the eval BatchNorm -> LeakyReLU that precedes conv1 of a pre-activation residual unit
+ * (handoccnet_light/hand_head.py:131-136,170-175) folded into the convolution's operand staging instead of a launch of
+ * hands_bn_leaky_f32 plus a round trip of the activations.  pre_scale / pre_shift: Cin floats (hands_fold_bn_f32 of a unit
+ * weight).  S > 1: the same with the deterministic S-slice split-K (workspace as for hands_conv2d_nhwc_splitk_n_f32).
+ * Bit-identical to hands_bn_leaky_f32 followed by the plain / split-K launch. */
+int hands_conv2d_nhwc_pre_f32(const hands_conv_desc* desc, const float* in, const float* pre_scale, const float* pre_shift,
+                              const float* w_packed, const float* bias, const float* residual, float* out, int S,
+                              float* workspace, long long workspace_floats, hands_stream_t stream);
+
 /* The same split-K as ONE launch: `counters` (>= one int per output tile of the launch: ceil(M/128)*ceil(Cout/128), or
  * ceil(M/256) for Cout <= 64; zero before the first use, left zero by every launch) lets the LAST slice of a tile to
  * arrive add the S partial tiles in ascending slice order and apply bias / residual / activation -- exactly the

@@ -169,3 +169,43 @@ def test_handoccnet_full_size_batch_independence_and_parity(hon_gpu, bz):
         verr = (big[f"mano.vertices.{hn}"][bz - 1:].cpu() - ref[f"mano.vertices.{hn}"]).abs().max().item()
         mp = O.mpjpe_ra_mm(big[f"mano.joints3d.{hn}"][bz - 1:].cpu(), ref[f"mano.joints3d.{hn}"])
         assert verr < 1e-6 and mp < 1e-3, (hn, verr, mp)
+
+
+@pytest.mark.parametrize("case", [(64, 32, 32, 128, 1), (64, 8, 8, 128, 2), (37, 5, 7, 64, 1), (64, 4, 4, 256, 2)])
+def test_preactivation_folded_into_the_convolution_is_bit_identical(case):
+    """hands_conv2d_nhwc_pre_f32: leaky_relu(bn(x)) applied to the operand of the unit's first (pointwise) convolution on
+    its way into LDS (hand_head.py:131-136,170-175) == hands_bn_leaky_f32 followed by the plain / split-K launch, bit for
+    bit; and the whole forward is bit-identical with the fusion on and off."""
+    from hands_amd.engine import ConvEngine
+    from hands_amd.packing import pack_conv
+    L = _lib.lib()
+    B, H, W, Cout, S = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, W, 256, generator=g).to(DEV)
+    sc, sh = (1 + 0.2 * torch.randn(256, generator=g)).to(DEV), (0.3 * torch.randn(256, generator=g)).to(DEV)
+    pc = pack_conv(torch.randn(Cout, 256, 1, 1, generator=g) / 16, torch.randn(Cout, generator=g), 1, 0, DEV)
+    res = torch.randn(B, H, W, pc.Cout, generator=g).to(DEV)
+    eng = ConvEngine()
+    t0 = torch.empty_like(x)
+    check(L.hands_bn_leaky_f32(ptr(x), ptr(sc), ptr(sh), ptr(t0), B * H * W, 256, _stream()))
+    a = torch.full((B, H, W, pc.Cout), float("nan"), device=DEV)
+    b = torch.full((B, H, W, pc.Cout), float("nan"), device=DEV)
+    eng.conv(L, pc, t0, B, H, W, a, 3, _stream(), res=res, splitk_n=S)
+    eng.conv(L, pc, x, B, H, W, b, 3, _stream(), res=res, splitk_n=S, pre=(sc, sh))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    ref = F.leaky_relu(F.leaky_relu(x.double().cpu() * sc.double().cpu() + sh.double().cpu(), 0.01) @
+                       pc.w[:pc.Cout, :256].double().cpu().T + pc.bias[:pc.Cout].double().cpu() + res.double().cpu(), 0.01)
+    assert (b.double().cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_handoccnet_forward_is_bit_identical_without_the_folded_preactivation(hon_gpu):
+    inputs, meta_info = synthetic_inputs(3, 8, device=DEV)
+    a = {k: v.clone() for k, v in hon_gpu(inputs, meta_info).items()}
+    hon_gpu.engine.fuse_pre = False
+    try:
+        b = {k: v.clone() for k, v in hon_gpu(inputs, meta_info).items()}
+    finally:
+        hon_gpu.engine.fuse_pre = True
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
