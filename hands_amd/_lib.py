@@ -57,6 +57,8 @@ class EvalOut(C.Structure):
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
     "hands_conv2d_nhwc_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P],
+    "hands_conv3x3_winograd_supported": [C.POINTER(ConvDesc)],
+    "hands_conv3x3_winograd_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
     "hands_bottleneck_link_f32": [_P, _P, _P, _P, _P, _P, _P, _P, C.c_longlong, _I, _P],
     "hands_conv2d_splitk_factor": [C.POINTER(ConvDesc)],
     "hands_conv2d_nhwc_splitk_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_longlong, _P],
@@ -112,8 +114,9 @@ SIGNATURES = {
     "hands_pack_linear_f64": [_I, _I, _P, _P, _P, _I, _P, _I, _P, _P],
     "hands_pack_conv1x1_dual_f64": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
     "hands_pack_mano_f32": [_P] * 10,
+    "hands_pack_conv3x3_winograd_f64": [_I, _I, _P, _P],
 }
-EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string", "hands_conv2d_workspace_floats",
+EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string", "hands_conv2d_workspace_floats", "hands_pack_conv3x3_winograd_floats",
                  "hands_conv2d_streamk_workspace_bytes", "hands_stream_is_capturing")
 
 _lib = None
@@ -137,6 +140,8 @@ def lib():
     h.hands_conv2d_workspace_floats.argtypes = [C.POINTER(ConvDesc), C.c_int]
     h.hands_conv2d_streamk_workspace_bytes.restype = C.c_longlong
     h.hands_conv2d_streamk_workspace_bytes.argtypes = []
+    h.hands_pack_conv3x3_winograd_floats.restype = C.c_longlong
+    h.hands_pack_conv3x3_winograd_floats.argtypes = [C.c_int, C.c_int]
     h.hands_abi_version.restype = C.c_int
     h.hands_stream_is_capturing.restype = C.c_int
     h.hands_stream_is_capturing.argtypes = [C.c_void_p]

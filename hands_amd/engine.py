@@ -35,6 +35,9 @@ class ConvEngine:
         self.math = "fp32"            # "fp32" = exact fp32 MFMA (the parity path, the default).  "bf16x3" = separately
                                       # reported mode: operands split into three exact bf16 planes, six bf16 MFMAs per
                                       # k-16 step with fp32 accumulation (HANDS_MATH_BF16X3); never the headline
+        self.winograd = True          # 3x3 / stride 1 / pad 1 layers as Winograd F(2x2,3x3) on the fp32 matrix cores
+                                      # (hands_conv3x3_winograd_f32: 2.25x fewer multiplications; fp32 throughout, results
+                                      # differ from the direct kernel by fp32 rounding).  False = the direct implicit GEMM
         self.fuse_mano = True         # MANOHead.forward of both hands as one launch (hands_mano_heads_f32)
         self.fuse_pre = True          # handoccnet_light's pre-activation units: BatchNorm -> LeakyReLU folded into the operand
                                       # staging of the unit's first (pointwise) convolution (hands_conv2d_nhwc_pre_f32)
@@ -60,7 +63,7 @@ class ConvEngine:
 
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
-        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "fuse_mano", "fuse_pre", "fuse_link", "fuse_splitk_reduce", "stream_k", "math"):
+        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "winograd", "fuse_mano", "fuse_pre", "fuse_link", "fuse_splitk_reduce", "stream_k", "math"):
             setattr(e, k, getattr(self, k))
         return e
 
@@ -131,6 +134,15 @@ class ConvEngine:
             tiles = -(-(B * Ho * Wo) // bm) * -(-pc.Cout // bn)
             S = max(S, min(256 // tiles, pc.Kpad // 128, 32)) if tiles <= 128 else S
         rp = ptr(res, res_off) if res is not None else None
+        if (self.winograd and pc.wino is not None and res is None and pre is None and S <= 1 and self.math == "fp32"
+                and L.hands_conv3x3_winograd_supported(C.byref(d))):
+            if hook is not None:
+                hook("begin", pc, B * Ho * Wo, stream, False, "conv_wino_f32_kernel")
+            check(L.hands_conv3x3_winograd_f32(C.byref(d), ptr(x, x_off), ptr(pc.wino), ptr(pc.bias), ptr(out, out_off), stream),
+                  "hands_conv3x3_winograd_f32")
+            if hook is not None:
+                hook("end", pc, B * Ho * Wo, stream, False, "conv_wino_f32_kernel")
+            return Ho, Wo
         if pre is not None:
             # pointwise layer behind an eval BatchNorm -> LeakyReLU (pre = (scale, shift) device vectors): the affine +
             # activation is applied to the operand on its way into LDS (hands_conv2d_nhwc_pre_f32)

@@ -37,6 +37,7 @@ class PackedConv:
     pad: int
     Kpad: int
     macs_per_pixel: int = 0   # ALGORITHMIC multiply-accumulates per output pixel (true, unpadded dims)
+    wino: torch.Tensor = None  # 3x3 / stride 1 / pad 1 layers: Winograd F(2x2,3x3) weights (hands_pack_conv3x3_winograd_f64)
 
 
 def _f64(t):
@@ -69,8 +70,9 @@ def fold_bn(w, bn_w, bn_b, bn_mean, bn_var, eps=BN_EPS):
     return torch.from_numpy(wf), torch.from_numpy(bf)
 
 
-def pack_conv(w, bias, stride, pad, device, cin_pad_to=None) -> PackedConv:
-    """w: (Cout, Cin, KH, KW) (any float dtype, CPU); bias: (Cout,) or None.  hands_pack_conv_f64."""
+def pack_conv(w, bias, stride, pad, device, cin_pad_to=None, winograd=True) -> PackedConv:
+    """w: (Cout, Cin, KH, KW) (any float dtype, CPU); bias: (Cout,) or None.  hands_pack_conv_f64.
+    3x3 / stride 1 / pad 1 layers additionally get the Winograd form of the same folded weight (``pc.wino``)."""
     L = _lib.lib()
     Cout, Cin, KH, KW = w.shape
     d = PackedDims()
@@ -80,8 +82,15 @@ def pack_conv(w, bias, stride, pad, device, cin_pad_to=None) -> PackedConv:
     bp = np.empty(d.Cout_pad, np.float32)
     check(L.hands_pack_conv_f64(Cout, Cin, KH, KW, int(cin_pad_to or 0), _p(wn), _p(bn), _p(wp), _p(bp)),
           "hands_pack_conv_f64")
-    return PackedConv(torch.from_numpy(wp).to(device), torch.from_numpy(bp).to(device), d.Cin, d.Cout, KH, KW,
-                      stride, pad, d.Kpad, macs_per_pixel=Cout * Cin * KH * KW)
+    pc = PackedConv(torch.from_numpy(wp).to(device), torch.from_numpy(bp).to(device), d.Cin, d.Cout, KH, KW,
+                    stride, pad, d.Kpad, macs_per_pixel=Cout * Cin * KH * KW)
+    if winograd and KH == 3 and KW == 3 and stride == 1 and pad == 1 and not cin_pad_to:
+        n = L.hands_pack_conv3x3_winograd_floats(Cout, Cin)
+        if n > 0:
+            up = np.empty(n, np.float32)
+            check(L.hands_pack_conv3x3_winograd_f64(Cout, Cin, _p(wn), _p(up)), "hands_pack_conv3x3_winograd_f64")
+            pc.wino = torch.from_numpy(up).to(device)
+    return pc
 
 
 def pack_conv1x1_dual(w0, b0, w1, b1, device) -> PackedConv:

@@ -83,6 +83,18 @@ int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, const float
                           const float* bias, const float* residual, float* out,
                           hands_stream_t stream);
 
+/* 3x3 / stride 1 / pad 1 convolution (+ folded BatchNorm bias + activation) as Winograd F(2x2, 3x3) on the fp32 matrix
+ * cores (csrc/conv_wino.hip): 16 instead of 36 multiplications per 2x2 output pixels and (cin, cout) pair.  Same layer
+ * semantics as hands_conv2d_nhwc_f32 with desc.KH = KW = 3, stride 1, pad 1 and no residual
+ * (conv2 / bn2 / relu of a stride-1 Bottleneck: src/nets/backbone/resnet.py:140-142); `u_packed` is the
+ * hands_pack_conv3x3_winograd_f64 form of the BN-folded weight, `bias` the same vector hands_pack_conv_f64 produced.
+ * All arithmetic is fp32 in a fixed, batch-size-independent order; the result differs from hands_conv2d_nhwc_f32 by
+ * fp32 rounding only (Winograd re-associates the 3x3 sum).  Requires Cin % 16 == 0, Cout % 32 == 0, act in
+ * {NONE, RELU, LEAKY_RELU}; hands_conv3x3_winograd_supported() returns 1 when `d` can take this route. */
+int hands_conv3x3_winograd_supported(const hands_conv_desc* d);
+int hands_conv3x3_winograd_f32(const hands_conv_desc* d, const float* in, const float* u_packed, const float* bias,
+                               float* out, hands_stream_t stream);
+
 /* The seam between two bottlenecks of layer1 as ONE launch (csrc/bottleneck_link.hip):
  *     out = relu(conv3_1x1(t2) + bn3 + identity)     src/nets/backbone/resnet.py:146-154 of block i     (64 -> 256)
  *     t1  = relu(conv1_1x1(out) + bn1)               src/nets/backbone/resnet.py:137-139 of block i + 1 (256 -> C1)
@@ -463,6 +475,9 @@ int hands_warp_affine_cubic_norm_f32(const float* src, const float* trans, float
  *                          permutations (the HMR state row, the grasp row, the NCHW nn.Flatten order).
  *   hands_pack_conv1x1_dual_f64  weight of hands_conv1x1_dual_nhwc_f32: [W0 | W1], bias b0 + b1.
  *   hands_pack_mano_f32    MANO constants (hands_mano_consts members + the blend GEMM weight/bias).
+ *   hands_pack_conv3x3_winograd_f64  U = G g G^T (fp64, rounded once) of a (Cout, Cin, 3, 3) weight in MFMA operand
+ *                          order for hands_conv3x3_winograd_f32; hands_pack_conv3x3_winograd_floats = 16 * Cout * Cin
+ *                          (0 if the shape is not supported: Cout % 32, Cin % 16).
  * hands_conv2d_workspace_floats: floats of split-K workspace hands_conv2d_nhwc_splitk_n_f32 needs for
  *   S slices (S <= 0: the library's own hands_conv2d_splitk_factor); 0 when no split is taken.
  * --------------------------------------------------------------------------------------------- */
@@ -488,6 +503,8 @@ int hands_pack_mano_f32(const float* v_template, const float* shapedirs, const f
                         float* J_template, float* J_shapedirs, float* blend_w_packed,
                         float* blend_bias_packed);
 long long hands_conv2d_workspace_floats(const hands_conv_desc* d, int S);
+long long hands_pack_conv3x3_winograd_floats(int Cout, int Cin);
+int hands_pack_conv3x3_winograd_f64(int Cout, int Cin, const double* w_oihw, float* u_packed);
 
 #ifdef __cplusplus
 }

@@ -488,3 +488,36 @@ def test_bench_launcher_stays_gpu_free_and_reports_the_failing_rank(monkeypatch,
     assert p.returncode not in (0, 2), p.stderr[-1500:]
     assert "LAUNCHER_TORCH=False" in p.stderr
     assert "bench.py launcher: rank" in p.stderr and "stderr (tail)" in p.stderr and "Traceback" in p.stderr
+
+
+def test_winograd_packer_layout_and_identity():
+    """hands_pack_conv3x3_winograd_f64 (csrc/pack.cpp): U = G g G^T in fp64, rounded once, in the MFMA-A operand order
+    [Cout/32][Cin/8][xi][nu][lane 64][4] that csrc/conv_wino.hip reads.  Checked against an independent numpy restatement
+    and, through A^T [U (.) B^T d B] A evaluated in fp64 FROM THE PACKED BUFFER, against F.conv2d."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(9)
+    Cout, Cin = 64, 32
+    w = torch.randn(Cout, Cin, 3, 3, generator=g).double()
+    pc = pack_conv(w, torch.randn(Cout, generator=g), 1, 1, "cpu")
+    assert pc.wino is not None and pc.wino.dtype == torch.float32 and pc.wino.numel() == 16 * Cout * Cin
+    assert pack_conv(w, None, 2, 1, "cpu").wino is None and pack_conv(w[:, :, :1, :1], None, 1, 0, "cpu").wino is None
+    assert pack_conv(w[:24], None, 1, 1, "cpu").wino is None          # Cout % 32 != 0: the direct kernel keeps the layer
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+    U = np.einsum("xi,ocij,nj->xnoc", G, w.numpy(), G)
+    up = pc.wino.numpy().reshape(Cout // 32, Cin // 8, 4, 4, 2, 32, 4)      # nb, c8, xi, nu, half, o, e
+    back = np.transpose(up, (2, 3, 0, 5, 1, 4, 6)).reshape(4, 4, Cout, Cin)     # xi, nu, (nb, o), (c8, half, e)
+    assert np.array_equal(back, U.astype(np.float32))
+    # the identity, from the packed weights
+    Bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
+    At = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
+    x = torch.randn(2, Cin, 6, 8, generator=g).double()
+    xp = F.pad(x, (1, 1, 1, 1)).numpy()
+    y = np.zeros((2, Cout, 6, 8))
+    for ty in range(3):
+        for tx in range(4):
+            d = xp[:, :, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]
+            V = np.einsum("xa,bcae,ne->bcxn", Bt, d, Bt)
+            M = np.einsum("bcxn,xnoc->boxn", V, back.astype(np.float64))
+            y[:, :, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = np.einsum("ix,boxn,jn->boij", At, M, At)
+    ref = F.conv2d(x, w, padding=1).numpy()
+    assert np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max()           # U is rounded to fp32 once

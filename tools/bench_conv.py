@@ -35,6 +35,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 eng = ConvEngine()
 eng.math = sys.argv[2] if len(sys.argv) > 2 else "fp32"
 eng.stream_k = os.environ.get("HANDS_STREAMK") == "1"
+eng.winograd = os.environ.get("HANDS_WINOGRAD", "1") == "1"
 L = _lib.lib()
 dev = "cuda"
 stream = torch.cuda.current_stream().cuda_stream
