@@ -290,6 +290,8 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         model.engine.fuse_pre = os.environ["HANDS_FUSE_PRE"] == "1"
     if os.environ.get("HANDS_FUSE_SPLITK"):        # developer A/B switch
         model.engine.fuse_splitk_reduce = os.environ["HANDS_FUSE_SPLITK"] == "1"
+    if os.environ.get("HANDS_WINOGRAD"):           # developer A/B switch (default: on)
+        model.engine.winograd = os.environ["HANDS_WINOGRAD"] == "1"
     if os.environ.get("HANDS_FUSE_LINK"):          # developer A/B switch
         model.engine.fuse_link = os.environ["HANDS_FUSE_LINK"] == "1"
     if os.environ.get("HANDS_ASYNC_FORWARD") and hasattr(model, "async_forward"):      # developer A/B switch

@@ -264,6 +264,7 @@ def test_stream_k_is_bit_identical_to_the_plain_launch(case):
     Ho = (H + 2 * pad - k) // stride + 1
     res = torch.randn(B, Ho, Ho, Cout, generator=g).to(DEV) if use_res else None
     plain, sk = ConvEngine(), ConvEngine()
+    plain.winograd = sk.winograd = False        # this test is about the direct kernel's two launch forms
     plain.stream_k, sk.stream_k = False, True
     ref = torch.full((B, Ho, Ho, pc.Cout), float("nan"), device=DEV)
     plain.conv(L, pc, x, B, H, H, ref, True, _stream(), res=res)
@@ -299,6 +300,7 @@ def test_stream_k_fallback_recomputes_the_same_bits(case):
     res = torch.randn(B, Ho, Ho, Cout, generator=g).to(DEV) if use_res else None
     plain = ConvEngine()
     plain.stream_k = False
+    plain.winograd = False                      # the reference is the direct kernel's plain launch
     ref = torch.full((B, Ho, Ho, pc.Cout), float("nan"), device=DEV)
     plain.conv(L, pc, x, B, H, H, ref, True, _stream(), res=res)
     d = _lib.ConvDesc(B, H, H, pc.Cin, Ho, Ho, pc.Cout, k, k, stride, pad, pc.Cin, pc.Cout, pc.Cout if use_res else 0, pc.Kpad, 1)
