@@ -393,7 +393,7 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
     k_flop = sum(d["flop"] for d in per.values()) / n_prof
     achieved = k_flop / (k_ms * 1e-3) / 1e12
     # the GEMM / convolution family (plain, stream-K and split-K launches of conv_igemm): what the PMC summaries cover
-    fam = [d for k, d in per.items() if k.startswith(("conv_igemm", "bottleneck_link"))]
+    fam = [d for k, d in per.items() if k.startswith(("conv_igemm", "conv_wino", "bottleneck_link"))]
     fam_launches = sum(d["launches"] for d in fam)
     fam_alg_gb = sum(d["bytes"] for d in fam) / max(fam_launches, 1) / 1e9
     traffic, traffic_src = pmc_traffic_per_launch(workload, bz)

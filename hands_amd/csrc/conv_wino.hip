@@ -26,6 +26,7 @@
 // src/nets/backbone/resnet.py:140-142 (conv2 / bn2 / relu of every stride-1 Bottleneck).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "hands_hip.h"
 #include "common.h"
 
@@ -44,7 +45,16 @@ struct WinoArgs {
   int in_ps, out_ps, act;
   int nblk_m, nblk_n, nseg;
   int rows;                         // B * nh flattened tile rows
+  int nbw, ngrp;                    // channel blocks per workgroup (divides nblk_n), groups = nblk_n / nbw
+  uint32_t nh_mul, nh_sh, ngrp_mul, ngrp_sh, nseg_mul, nseg_sh;   // host-computed magic numbers: x / nh, x / (nblk_n / nbw), x / nseg
 };
+
+// x / d for 0 <= x < 2^31 with M = ceil(2^(31 + l) / d), l = ceil(log2 d) >= 1 (Granlund-Montgomery: exact, M < 2^32);
+// d == 1 is encoded as M = 0.  A runtime integer division costs ~35 vector instructions and the tile setup has a dozen:
+// measured 9-11 k cycles of a workgroup's 38-123 k (tools/prof_wino.py)
+__device__ __forceinline__ int fastdiv(int x, uint32_t mul, uint32_t sh) {
+  return mul == 0 ? x : (int)(__umulhi((uint32_t)x, mul) >> sh);
+}
 
 __device__ __forceinline__ int wino_xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7;
@@ -77,24 +87,28 @@ struct WinoGeom {
   static constexpr int RP = 4 * PWP + 1;                        // pitch of a tile row's 4 input rows: odd, so consecutive
                                                                 // tile rows start in different bank classes
   static constexpr int NR = LINEAR ? (D - 1 + 32 + D - 1) / D : 32 / D;   // tile rows a block can touch
-  static constexpr int SLOTS = NR * RP * 4;                     // 16-byte slots of one 16-channel stage
-  static constexpr int NJW = (SLOTS + 63) / 64;                 // LDS-DMA wave instructions per stage
-  static constexpr int NJ = (NJW + 3) / 4;                      // per wave
-  static constexpr int BUF_FLOATS = NJW * 256;                  // 1 KB per wave instruction
+  // LDS-DMA pieces: one wave instruction = 16 pixels x 64 B of ONE input row (lane = pixel * 4 + 16-byte slot), so the
+  // row part of every source address is wave-uniform (scalar unit) and the lane part is computed once per workgroup
+  static constexpr int NP = (PWP + 15) / 16;                    // pieces per input row
+  static constexpr int NPIECE = NR * 4 * NP;
+  static constexpr int NJ = (NPIECE + 3) / 4;                   // per wave
+  static constexpr int BUF_FLOATS = ((NR * RP * 16 + 63) / 64) * 64;
 };
 
 #ifndef WINO_WAVES
 #define WINO_WAVES 3
 #endif
-constexpr int ZBUF_FLOATS = 4 * 2 * 32 * 32;                    // epilogue exchange: [xi][j][tile 32][32 channels]
+constexpr int ZROUND_FLOATS = 4 * 32 * 32;                      // epilogue exchange, one round: [xi][tile 32][32 channels]
 
-// One workgroup: 32 tiles x 32 output channels, all 16 frequencies, all input channels.
+// One workgroup: 32 tiles (128 output pixels) x `nbw` blocks of 32 output channels, one after the other on the same
+// patch (the tile setup and the first fill's latency are paid once; the stages of consecutive channel blocks form one
+// software pipeline).
 template <int D, bool LINEAR>
 __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs a) {
   using G = WinoGeom<D, LINEAR>;
-  // (at least 41 KB: 3 workgroups per CU is what the ~160 registers allow anyway, and hipcc then schedules for that)
+  // (at least 41 KB: 3 workgroups per CU is what the ~150 registers allow anyway, and hipcc then schedules for that)
   constexpr int LDS_FLOATS = 2 * G::BUF_FLOATS > 10496 ? 2 * G::BUF_FLOATS : 10496;
-  static_assert(LDS_FLOATS >= ZBUF_FLOATS, "the epilogue exchange reuses the patch buffers");
+  static_assert(G::BUF_FLOATS >= ZROUND_FLOATS, "the epilogue exchange reuses one patch buffer");
   __shared__ __attribute__((aligned(1024))) float lds[LDS_FLOATS];
 
   const int tid = threadIdx.x;
@@ -102,56 +116,70 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
   const int xi = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = frequency row
   const int l31 = lane & 31, half = lane >> 5;
 
-  const int ntiles = a.nblk_m * a.nblk_n;
-  const int tile = wino_xcd_remap(blockIdx.x, ntiles);
-  const int mb = tile / a.nblk_n, nb = tile - mb * a.nblk_n;    // n fastest: the channel blocks of one patch share an L2
+  const int ngrp = a.ngrp;                                      // channel-block groups per tile block
+  const int tile = wino_xcd_remap(blockIdx.x, a.nblk_m * ngrp);
+  const int mb = fastdiv(tile, a.ngrp_mul, a.ngrp_sh), nb0 = (tile - mb * ngrp) * a.nbw;   // group fastest: one patch, one L2
 
   int R0, s0, tx0;                                              // (all 32-bit: B * nh * nw < 2^31 is checked by the host)
   if constexpr (LINEAR) {
     const int t0 = mb * 32;
     R0 = t0 / D; s0 = t0 - R0 * D; tx0 = 0;
   } else {
-    const int rb = mb / a.nseg, seg = mb - rb * a.nseg;
+    const int rb = fastdiv(mb, a.nseg_mul, a.nseg_sh), seg = mb - rb * a.nseg;
     R0 = rb * G::NR; s0 = 0; tx0 = seg * D;
   }
-  const int b_first = R0 / a.nh;                                // first image this block touches (wave-uniform)
+  const int b_first = fastdiv(R0, a.nh_mul, a.nh_sh);           // first image this block touches (wave-uniform)
+  const int ty_first = R0 - b_first * a.nh;
 
-  // ---- LDS-DMA fill assignment: slot = j * 256 + tid  ->  (tile row, input row a, patch pixel x, 16-byte slot) ----
+  // ---- weights: MFMA-A fragments straight from L2, one 16-byte load per lane, frequency and 8-channel step; the steps of
+  //      consecutive channel blocks are contiguous, so one running scalar offset walks all of this workgroup's stages ----
+  const int nc8 = a.Cin >> 3;
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.u) + (size_t)nb0 * nc8 * 4096, 0, (int)0x80000000u, 0x00020000);
+  const int w_off = (xi * 1024 + lane * 4) * 4;
+  float4 wr[2][4];
+#define WINO_LOADW(SET, STEP)                                                                       \
+  do {                                                                                              \
+    _Pragma("unroll") for (int nu = 0; nu < 4; ++nu)                                                \
+      wr[SET][nu] = f4(__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_off + nu * 1024, (STEP) * 16384, 0)); \
+  } while (0)
+  WINO_LOADW(0, 0);
+
+  // ---- LDS-DMA fill: piece i = j * 4 + wave  ->  input row (i / NP) = (tile row Rl, row a of its 4), pixels 16 (i % NP) .. + 15.
+  //      Lane part (once): pixel x, source quad q = slot ^ ((x >> 1) & 3) (source-side swizzle: the DMA destination is
+  //      lane-linear), column validity.  Row part (scalar, per piece): image, input row, validity.  ----------------------
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.in) + (size_t)b_first * a.H * a.W * a.in_ps, 0, (int)0x80000000u, 0x00020000);
+  const int piece = (G::NP == 1) ? 0 : (xi % G::NP);            // (4 % NP == 0: a wave always gets the same piece of a row)
+  static_assert(4 % G::NP == 0, "pieces per row must divide the wave count");
+  const int fx = piece * 16 + (lane >> 2);                      // patch pixel of this lane
+  const int fwx = 2 * tx0 - 1 + fx;
+  const bool f_lane = fx < G::PWP;                              // lanes past the row's end write nothing (exec mask)
+  const int f_col = ((unsigned)fwx < (unsigned)a.W) ? (fwx * a.in_ps + (((lane & 3) ^ ((fx >> 1) & 3)) * 4)) * 4 : (int)0x80000000u;
   int f_off[G::NJ];
+  int f_dst[G::NJ];                                             // wave-uniform LDS float offset of the piece (-1: none)
 #pragma unroll
   for (int j = 0; j < G::NJ; ++j) {
-    const int slot = j * 256 + tid;
-    const int P = slot >> 2, qs = slot & 3;
-    const int Rl = P / G::RP, rem = P - Rl * G::RP;
-    const int ar = rem / G::PWP, x = rem - ar * G::PWP;
-    const int R = R0 + Rl;
-    const int b = R / a.nh, ty = R - b * a.nh;
-    const int hy = 2 * ty - 1 + ar, wx = 2 * tx0 - 1 + x;
-    const bool ok = Rl < G::NR && ar < 4 && R < a.rows && (unsigned)hy < (unsigned)a.H && (unsigned)wx < (unsigned)a.W;
-    const int q = qs ^ ((x >> 1) & 3);                          // source-side swizzle (the DMA destination is lane-linear)
-    f_off[j] = ok ? ((((b - b_first) * a.H + hy) * a.W + wx) * a.in_ps + q * 4) * 4 : (int)0x80000000u;
+    const int i = j * 4 + xi;
+    const int r = i / G::NP, fRl = r >> 2, ar = r & 3;
+    const int t = ty_first + fRl;
+    const int db = fastdiv(t, a.nh_mul, a.nh_sh), ty = t - db * a.nh;        // image b_first + db
+    const int hy = 2 * ty - 1 + ar;
+    const bool rowok = R0 + fRl < a.rows && (unsigned)hy < (unsigned)a.H;
+    const int rowoff = (db * a.H + hy) * a.W * a.in_ps * 4;
+    f_off[j] = (rowok && f_col >= 0) ? rowoff + f_col : (int)0x80000000u;
+    f_dst[j] = i < G::NPIECE ? (fRl * G::RP + ar * G::PWP + piece * 16) * 16 : -1;
   }
 #define WINO_FILL(BUF_OFF, CH)                                                                      \
   do {                                                                                              \
-    _Pragma("unroll") for (int j = 0; j < G::NJ; ++j) {                                             \
-      if ((j + 1) * 4 <= G::NJW || j * 4 + xi < G::NJW)          /* only the last one can be partial */ \
-        wino_dma16(x_rsrc, lds + (BUF_OFF) + (j * 4 + xi) * 256, f_off[j], (CH) * 64);                 \
+    if (f_lane) {                                                                                   \
+      _Pragma("unroll") for (int j = 0; j < G::NJ; ++j) {                                           \
+        if ((j + 1) * 4 <= G::NPIECE || f_dst[j] >= 0)           /* only the last one can be missing */ \
+          wino_dma16(x_rsrc, lds + (BUF_OFF) + f_dst[j], f_off[j], (CH) * 64);                      \
+      }                                                                                             \
     }                                                                                               \
   } while (0)
-
-  // ---- weights: MFMA-A fragments straight from L2, one 16-byte load per lane, frequency and 8-channel step ----
-  const int nc8 = a.Cin >> 3;
-  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.u) + (size_t)nb * nc8 * 4096, 0, (int)0x80000000u, 0x00020000);
-  const int w_off = (xi * 1024 + lane * 4) * 4;
-  float4 wr[2][4];
-#define WINO_LOADW(SET, C8)                                                                         \
-  do {                                                                                              \
-    _Pragma("unroll") for (int nu = 0; nu < 4; ++nu)                                                \
-      wr[SET][nu] = f4(__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_off + nu * 1024, (C8) * 16384, 0)); \
-  } while (0)
+  WINO_FILL(0, 0);
 
   // ---- this lane's tile and its patch read addresses ---------------------------------------------------------------
   const int qq = s0 + l31;
@@ -171,6 +199,18 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
     rd[1][bc] = (pix0 + a2 * G::PWP) * 64 + ((half ^ sw) * 16);
   }
   const char* ldsb = reinterpret_cast<const char*>(lds);
+
+  // ---- the output side of this thread: tile tl, channels 4 cq .. 4 cq + 3 of a block -------------------------------
+  const int tl = tid >> 3, cq = tid & 7;
+  const int q2 = s0 + tl;
+  const int Rl2 = q2 / D, col2 = q2 - Rl2 * D;
+  const int oR = R0 + Rl2, otx = tx0 + col2;
+  const int ob = fastdiv(oR, a.nh_mul, a.nh_sh), oty = oR - ob * a.nh;
+  const bool o_ok = oR < a.rows && otx < a.nw;
+  const bool o_row1 = 2 * oty + 1 < a.H, o_col1 = 2 * otx + 1 < a.W;
+  float* const o_base = a.out + (((size_t)ob * a.H + 2 * oty) * a.W + 2 * otx) * (size_t)a.out_ps + nb0 * 32 + cq * 4;
+  const int zpos = (tl * 8 + (cq ^ (tl & 7))) * 4;              // exchange buffer: quad cq of tile t at position cq ^ (t & 7)
+  const int zwr = (l31 * 8) * 4;
 
   f32x16 acc[4];
 #pragma unroll
@@ -194,89 +234,103 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
     }                                                                                               \
   } while (0)
 
-  // stage ch lives in buffer ch & 1; its DMA was issued one stage ahead.  One barrier per stage (32 MFMAs per wave).
+  // Stage s = (channel block s / nch, 16 channels s % nch) lives in buffer s & 1; its DMA and the weights of its first
+  // step were issued one stage ahead -- also across the end of a channel block.  One barrier per stage (32 MFMAs per wave).
   const int nch = a.Cin >> 4;
-  WINO_FILL(0, 0);
-  WINO_LOADW(0, 0);
+  const int nst = nch * a.nbw;
   __syncthreads();                       // (the compiler's fence waits for this wave's DMA)
-  for (int ch = 0; ch < nch; ++ch) {
-    const int boff = (ch & 1) * (G::BUF_FLOATS * 4);           // bytes (a multiple of 1024: the ^ 32 of step 1 is unaffected)
-    const int foff = ((ch & 1) ^ 1) * G::BUF_FLOATS;
-    if (ch + 1 < nch) WINO_FILL(foff, ch + 1);
-    WINO_LOADW(1, 2 * ch + 1);
+  int ch = 0, nbi = 0;
+  for (int s = 0; s < nst; ++s) {
+    const int boff = (s & 1) * (G::BUF_FLOATS * 4);            // bytes (a multiple of 256: the ^ 32 of step 1 is unaffected)
+    const int foff = ((s & 1) ^ 1) * G::BUF_FLOATS;
+    const int chn = ch + 1 == nch ? 0 : ch + 1;
+    if (s + 1 < nst) WINO_FILL(foff, chn);
+    WINO_LOADW(1, 2 * s + 1);
+    __builtin_amdgcn_sched_barrier(0);                         // (hipcc otherwise sinks the loads to their first use)
     WINO_STEP(boff, 0, 0);
-    WINO_LOADW(0, ch + 1 < nch ? 2 * ch + 2 : 2 * ch + 1);     // (the last stage re-loads a valid step: no branch)
+    WINO_LOADW(0, s + 1 < nst ? 2 * s + 2 : 2 * s + 1);        // (the last stage re-loads a valid step: no branch)
+    __builtin_amdgcn_sched_barrier(0);
     WINO_STEP(boff, 1, 1);
     __syncthreads();
+    ch = chn;
+    if (ch != 0) continue;
+
+    // ---- end of a channel block: nu half of A^T . A in registers, xi half through this stage's (now idle) patch buffer in
+    //      two rounds (output columns j = 0, 1), bias + activation, 16-byte NHWC stores.  Accumulator register r of a lane:
+    //      channel 8 (r >> 2) + 4 half + (r & 3) of tile l31.  The next stage's patch is already arriving in the other buffer.
+    float* sZ = lds + (s & 1) * G::BUF_FLOATS;
+    const int n = (nb0 + nbi) * 32 + cq * 4;
+    const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 z;
+        if (j == 0) {
+          z.x = (acc[0][4 * g + 0] + acc[1][4 * g + 0]) + acc[2][4 * g + 0];
+          z.y = (acc[0][4 * g + 1] + acc[1][4 * g + 1]) + acc[2][4 * g + 1];
+          z.z = (acc[0][4 * g + 2] + acc[1][4 * g + 2]) + acc[2][4 * g + 2];
+          z.w = (acc[0][4 * g + 3] + acc[1][4 * g + 3]) + acc[2][4 * g + 3];
+        } else {
+          z.x = (acc[1][4 * g + 0] - acc[2][4 * g + 0]) - acc[3][4 * g + 0];
+          z.y = (acc[1][4 * g + 1] - acc[2][4 * g + 1]) - acc[3][4 * g + 1];
+          z.z = (acc[1][4 * g + 2] - acc[2][4 * g + 2]) - acc[3][4 * g + 2];
+          z.w = (acc[1][4 * g + 3] - acc[2][4 * g + 3]) - acc[3][4 * g + 3];
+        }
+        *reinterpret_cast<float4*>(sZ + xi * 1024 + zwr + (((2 * g + half) ^ (l31 & 7)) * 4)) = z;
+      }
+      __syncthreads();
+      if (o_ok && (j == 0 || o_col1)) {
+        const float4 z0 = *reinterpret_cast<const float4*>(sZ + 0 * 1024 + zpos);
+        const float4 z1 = *reinterpret_cast<const float4*>(sZ + 1 * 1024 + zpos);
+        const float4 z2 = *reinterpret_cast<const float4*>(sZ + 2 * 1024 + zpos);
+        const float4 z3 = *reinterpret_cast<const float4*>(sZ + 3 * 1024 + zpos);
+        float4 y0 = add4(add4(add4(z0, z1), z2), bv);
+        float4 y1 = add4(sub4(sub4(z1, z2), z3), bv);
+        if (a.act == HANDS_ACT_RELU) {
+          y0.x = fmaxf(y0.x, 0.f); y0.y = fmaxf(y0.y, 0.f); y0.z = fmaxf(y0.z, 0.f); y0.w = fmaxf(y0.w, 0.f);
+          y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);
+        } else if (a.act == HANDS_ACT_LEAKY_RELU) {
+          y0.x = y0.x > 0.f ? y0.x : 0.01f * y0.x; y0.y = y0.y > 0.f ? y0.y : 0.01f * y0.y;
+          y0.z = y0.z > 0.f ? y0.z : 0.01f * y0.z; y0.w = y0.w > 0.f ? y0.w : 0.01f * y0.w;
+          y1.x = y1.x > 0.f ? y1.x : 0.01f * y1.x; y1.y = y1.y > 0.f ? y1.y : 0.01f * y1.y;
+          y1.z = y1.z > 0.f ? y1.z : 0.01f * y1.z; y1.w = y1.w > 0.f ? y1.w : 0.01f * y1.w;
+        }
+        float* o = o_base + (size_t)nbi * 32 + (size_t)j * a.out_ps;
+        *reinterpret_cast<float4*>(o) = y0;
+        if (o_row1) *reinterpret_cast<float4*>(o + (size_t)a.W * a.out_ps) = y1;
+      }
+      __syncthreads();                    // round 1 reuses the region; after round 1 the next stage's DMA may overwrite it
+    }
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
+    ++nbi;
   }
 #undef WINO_STEP
 #undef WINO_LOADW
 #undef WINO_FILL
-
-  // ---- epilogue: nu half of A^T . A in registers, xi half through LDS, bias + activation, 16-byte NHWC stores -----
-  // accumulator register r of a lane: channel 8 (r >> 2) + 4 half + (r & 3) of tile l31
-  {
-    float* sZ = lds;                     // [xi][j][tile][8 quads], quad cq of tile t at position cq ^ (t & 7)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 z0, z1;
-      z0.x = (acc[0][4 * g + 0] + acc[1][4 * g + 0]) + acc[2][4 * g + 0];
-      z0.y = (acc[0][4 * g + 1] + acc[1][4 * g + 1]) + acc[2][4 * g + 1];
-      z0.z = (acc[0][4 * g + 2] + acc[1][4 * g + 2]) + acc[2][4 * g + 2];
-      z0.w = (acc[0][4 * g + 3] + acc[1][4 * g + 3]) + acc[2][4 * g + 3];
-      z1.x = (acc[1][4 * g + 0] - acc[2][4 * g + 0]) - acc[3][4 * g + 0];
-      z1.y = (acc[1][4 * g + 1] - acc[2][4 * g + 1]) - acc[3][4 * g + 1];
-      z1.z = (acc[1][4 * g + 2] - acc[2][4 * g + 2]) - acc[3][4 * g + 2];
-      z1.w = (acc[1][4 * g + 3] - acc[2][4 * g + 3]) - acc[3][4 * g + 3];
-      const int cq = 2 * g + half;
-      const int pos = (l31 * 8 + (cq ^ (l31 & 7))) * 4;
-      *reinterpret_cast<float4*>(sZ + (xi * 2 + 0) * 1024 + pos) = z0;
-      *reinterpret_cast<float4*>(sZ + (xi * 2 + 1) * 1024 + pos) = z1;
-    }
-  }
-  __syncthreads();
-  {
-    const float* sZ = lds;
-    const int tl = tid >> 3, cq = tid & 7;           // output: tile tl, channels 4 cq .. 4 cq + 3 of this block's 32
-    const int pos = (tl * 8 + (cq ^ (tl & 7))) * 4;
-    float4 z[4][2];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) z[x][j] = *reinterpret_cast<const float4*>(sZ + (x * 2 + j) * 1024 + pos);
-    const int q2 = s0 + tl;
-    const int Rl2 = q2 / D, col2 = q2 - Rl2 * D;
-    const int R = R0 + Rl2;
-    const int tx = tx0 + col2;
-    if (R < a.rows && tx < a.nw) {
-      const int b = R / a.nh, ty = R - b * a.nh;
-      const int n = nb * 32 + cq * 4;
-      const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
-      const int act = a.act;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int oy = 2 * ty + i;
-        if (oy >= a.H) continue;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int ox = 2 * tx + j;
-          if (ox >= a.W) continue;
-          float4 y = i == 0 ? add4(add4(z[0][j], z[1][j]), z[2][j]) : sub4(sub4(z[1][j], z[2][j]), z[3][j]);
-          y = add4(y, bv);
-          if (act == HANDS_ACT_RELU) {
-            y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
-          } else if (act == HANDS_ACT_LEAKY_RELU) {
-            y.x = y.x > 0.f ? y.x : 0.01f * y.x; y.y = y.y > 0.f ? y.y : 0.01f * y.y;
-            y.z = y.z > 0.f ? y.z : 0.01f * y.z; y.w = y.w > 0.f ? y.w : 0.01f * y.w;
-          }
-          *reinterpret_cast<float4*>(a.out + (((size_t)b * a.H + oy) * a.W + ox) * (size_t)a.out_ps + n) = y;
-        }
-      }
-    }
-  }
 }
 
 }  // namespace
+
+static int wino_device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cus;
+}
+
+static void wino_magic(int d, uint32_t& mul, uint32_t& sh) {
+  if (d <= 1) { mul = 0; sh = 0; return; }
+  int l = 0;
+  while ((1LL << l) < d) ++l;                                   // l = ceil(log2 d) >= 1
+  mul = (uint32_t)(((1ULL << (31 + l)) + (uint64_t)d - 1) / (uint64_t)d);
+  sh = (uint32_t)(l - 1);                                       // (x * mul) >> (31 + l) = umulhi(x, mul) >> (l - 1)
+}
 
 template <int D, bool LINEAR>
 static int wino_launch(WinoArgs& a, hipStream_t stream) {
@@ -292,9 +346,31 @@ static int wino_launch(WinoArgs& a, hipStream_t stream) {
     nblk_m = (rows + G::NR - 1) / G::NR * a.nseg;
   }
   a.nblk_n = a.Cout / 32;
-  const long long nwg = nblk_m * a.nblk_n;
-  if (nwg <= 0 || nwg > 0x7fffffffLL) return HANDS_EINVAL;
+  if (nblk_m <= 0 || nblk_m * a.nblk_n > 0x7fffffffLL) return HANDS_EINVAL;
   a.nblk_m = (int)nblk_m;
+  // Channel blocks per workgroup: a workgroup pays ~10 k cycles of tile setup once and ~5 k per channel block (epilogue)
+  // next to ~6.5 k per 16-channel stage (tools/prof_wino.py), so short-K layers want several channel blocks per
+  // workgroup -- but fewer, longer workgroups quantise worse on the chip's 3 x CUs slots.  Cheapest divisor of nblk_n under
+  // that model (a function of the launch geometry only: the arithmetic and its order never depend on it).
+  const long long slots = 3LL * wino_device_cus();
+  const double nch = a.Cin / 16;
+  double best = 0.0;
+  a.nbw = 1;
+  for (int w = 1; w <= a.nblk_n; ++w) {
+    if (a.nblk_n % w) continue;
+    const long long wgs = nblk_m * (a.nblk_n / w);
+    const double cost = (double)((wgs + slots - 1) / slots) * (10.0 + w * (6.5 * nch + 5.0));
+    if (w == 1 || cost < best) { best = cost; a.nbw = w; }
+  }
+  if (const char* e = getenv("HANDS_WINO_NBW")) {               // developer override (must divide Cout / 32)
+    const int w = atoi(e);
+    if (w >= 1 && a.nblk_n % w == 0) a.nbw = w;
+  }
+  const int ngrp = a.ngrp = a.nblk_n / a.nbw;
+  const long long nwg = nblk_m * ngrp;
+  wino_magic(a.nh, a.nh_mul, a.nh_sh);
+  wino_magic(ngrp, a.ngrp_mul, a.ngrp_sh);
+  wino_magic(a.nseg, a.nseg_mul, a.nseg_sh);
   // 32-bit byte offsets from the first image a block touches
   const long long imgs = G::NR / a.nh + 2;
   if (imgs * a.H * a.W * a.in_ps * 4 >= 0x7fffffffLL) return HANDS_EINVAL;
@@ -322,7 +398,7 @@ extern "C" int hands_conv3x3_winograd_f32(const hands_conv_desc* d, const float*
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.act = d->act & HANDS_ACT_MASK;
   if ((long long)d->B * a.nh >= 0x7fffff00LL) return HANDS_EINVAL;
   a.rows = d->B * a.nh;
-  a.nblk_m = a.nblk_n = a.nseg = 0;
+  a.nblk_m = a.nblk_n = a.nseg = a.nbw = a.ngrp = 0;
   hipStream_t s = (hipStream_t)stream;
   if (a.nw == 7) return wino_launch<7, true>(a, s);
   if (a.nw % 4 == 0 || a.nw < 8) return wino_launch<4, false>(a, s);

@@ -18,7 +18,7 @@ if [ -n "$REPL" ]; then cp $REPL $D/${4:-conv_igemm.hip}; fi
 cd $D
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I. -fno-fast-math -ffp-contract=off -Wno-unused-function $EXTRA_FLAGS"   # EXTRA_FLAGS: e.g. -DHANDS_EPI_SCALAR_ADDS
 OBJS=""
-for f in *.hip; do /opt/rocm/bin/hipcc $FLAGS -c $f -o ${f%.hip}.o & OBJS="$OBJS ${f%.hip}.o"; done
+for f in *.hip; do X=""; if [ "$f" = "conv_wino.hip" ]; then X="-fno-slp-vectorize"; fi; /opt/rocm/bin/hipcc $FLAGS $X -c $f -o ${f%.hip}.o & OBJS="$OBJS ${f%.hip}.o"; done
 wait
 if [ -f pack.cpp ]; then /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -I. -fno-fast-math -ffp-contract=off -x c++ -c pack.cpp -o pack.o; OBJS="$OBJS pack.o"; fi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $R/build_ab/$N.so

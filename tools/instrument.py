@@ -21,6 +21,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONV = os.path.join(ROOT, "hands_amd", "csrc", "conv_igemm.hip")
 STEM = os.path.join(ROOT, "hands_amd", "csrc", "stem_pool.hip")
+WINO = os.path.join(ROOT, "hands_amd", "csrc", "conv_wino.hip")
 
 
 def sub(s, old, new, what):
@@ -127,7 +128,42 @@ def stem_phases():
     return head + body, "stem_pool.hip"
 
 
-KINDS = {"tile": (conv_tile_timeline, "prof_tile"), "clock": (conv_clock, "prof_clock"), "ring": (conv_ring, "prof_ring"),
+def wino_phases():
+    """conv_wino: s_memtime (shader cycles) of wave 0 at entry / before the first barrier / after it / at exit, plus the
+    summed duration of the per-channel-block epilogues (tools/prof_wino.py)"""
+    s = open(WINO).read()
+    s = sub(s, "namespace {\n\ntypedef float f32x16", """__device__ unsigned long long g_wprof[32768 * 8];
+extern "C" int hands_debug_wprof(void* dst) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wprof), sizeof(unsigned long long) * 32768 * 8);
+  hipMemset((void*)0, 0, 0);
+  return 0;
+}
+extern "C" int hands_debug_wprof_clear() {
+  static unsigned long long z[32768 * 8];
+  hipDeviceSynchronize();
+  hipMemcpyToSymbol(HIP_SYMBOL(g_wprof), z, sizeof(z));
+  return 0;
+}
+namespace {
+
+typedef float f32x16""", "globals")
+    st = ("__builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 32768) g_wprof[blockIdx.x * 8 + %d] = "
+          "__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);")
+    s = sub(s, "  const int tid = threadIdx.x;\n  const int lane = tid & 63;\n  const int xi =", "  " + st % 0 +
+            "\n  unsigned long long epi_t = 0, epi_0 = 0;\n  const int tid = threadIdx.x;\n  const int lane = tid & 63;\n  const int xi =", "entry")
+    s = sub(s, "  __syncthreads();                       // (the compiler's fence waits for this wave's DMA)\n",
+            "  " + st % 1 + "\n  __syncthreads();\n  " + st % 2 + "\n", "prologue")
+    s = sub(s, "    float* sZ = lds + (s & 1) * G::BUF_FLOATS;\n",
+            "    __builtin_amdgcn_sched_barrier(0); epi_0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);\n"
+            "    float* sZ = lds + (s & 1) * G::BUF_FLOATS;\n", "epilogue start")
+    s = sub(s, "    ++nbi;\n  }\n", "    ++nbi;\n    __builtin_amdgcn_sched_barrier(0); epi_t += __builtin_amdgcn_s_memtime() - epi_0; "
+            "__builtin_amdgcn_sched_barrier(0);\n  }\n  " + st % 5 +
+            "\n  if (threadIdx.x == 0 && blockIdx.x < 32768) g_wprof[blockIdx.x * 8 + 4] = epi_t;\n", "exit")
+    return s, "conv_wino.hip"
+
+
+KINDS = {"wino": (wino_phases, "prof_wino"), "tile": (conv_tile_timeline, "prof_tile"), "clock": (conv_clock, "prof_clock"), "ring": (conv_ring, "prof_ring"),
          "stem": (stem_phases, "prof_stem")}
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ for d in ("a","b"):
     for fn in glob.glob("$O/%s/**/*counter_collection.csv"%d, recursive=True):
         acc=collections.defaultdict(float); n=set()
         for r in csv.DictReader(open(fn)):
-            if "conv_igemm" in r["Kernel_Name"]:
+            if "conv_igemm" in r["Kernel_Name"] or "conv_wino" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]]+=float(r["Counter_Value"]); n.add(r["Dispatch_Id"])
         print("$M", d, len(n), {k: "%.4g"%(v/len(n)) for k,v in acc.items()})
 PY

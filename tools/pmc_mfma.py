@@ -8,7 +8,7 @@ import collections
 import csv
 import sys
 
-FAMILIES = ("conv_igemm", "bottleneck_link", "stem_pool", "flash_attention64", "attention_kernel", "cross_attention", "mano_heads")
+FAMILIES = ("conv_igemm", "conv_wino", "bottleneck_link", "stem_pool", "flash_attention64", "attention_kernel", "cross_attention", "mano_heads")
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for r in csv.DictReader(open(sys.argv[1])):

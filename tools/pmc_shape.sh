@@ -24,7 +24,7 @@ import csv,glob,collections
 acc=collections.defaultdict(float); cnt=collections.defaultdict(set)
 for fn in glob.glob("$O/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
-        if "conv_igemm" in r["Kernel_Name"]:
+        if "conv_igemm" in r["Kernel_Name"] or "conv_wino" in r["Kernel_Name"]:
             acc[r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[r["Counter_Name"]].add(r["Dispatch_Id"])
 print("shape $SH")
 for k in sorted(acc): print("  %-34s %.5g" % (k, acc[k]/max(len(cnt[k]),1)))
