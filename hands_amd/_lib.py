@@ -116,7 +116,7 @@ SIGNATURES = {
     "hands_pack_mano_f32": [_P] * 10,
     "hands_pack_conv3x3_winograd_f64": [_I, _I, _P, _P],
 }
-EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string", "hands_conv2d_workspace_floats", "hands_pack_conv3x3_winograd_floats",
+EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string", "hands_conv2d_workspace_floats", "hands_pack_conv3x3_winograd_floats", "hands_conv3x3_winograd_executed_macs",
                  "hands_conv2d_streamk_workspace_bytes", "hands_stream_is_capturing")
 
 _lib = None
@@ -142,6 +142,8 @@ def lib():
     h.hands_conv2d_streamk_workspace_bytes.argtypes = []
     h.hands_pack_conv3x3_winograd_floats.restype = C.c_longlong
     h.hands_pack_conv3x3_winograd_floats.argtypes = [C.c_int, C.c_int]
+    h.hands_conv3x3_winograd_executed_macs.restype = C.c_longlong
+    h.hands_conv3x3_winograd_executed_macs.argtypes = [C.POINTER(ConvDesc)]
     h.hands_abi_version.restype = C.c_int
     h.hands_stream_is_capturing.restype = C.c_int
     h.hands_stream_is_capturing.argtypes = [C.c_void_p]

@@ -388,6 +388,18 @@ static bool wino_ok(const hands_conv_desc* d) {
 
 extern "C" int hands_conv3x3_winograd_supported(const hands_conv_desc* d) { return d && wino_ok(d) ? 1 : 0; }
 
+// Multiply-accumulates the matrix cores really execute for this layer (idle tile lanes included): 16 frequencies x 32-tile
+// blocks x Cin x Cout.  The algorithmic count of the layer is 9 * H * W * Cin * Cout per image: bench.py reports both.
+extern "C" long long hands_conv3x3_winograd_executed_macs(const hands_conv_desc* d) {
+  if (!d || !wino_ok(d)) return 0;
+  const long long nh = (d->H + 1) / 2, nw = (d->W + 1) / 2, rows = (long long)d->B * nh;
+  long long nblk_m;
+  if (nw == 7) nblk_m = (rows * 7 + 31) / 32;
+  else if (nw % 4 == 0 || nw < 8) nblk_m = (rows + 7) / 8 * ((nw + 3) / 4);
+  else nblk_m = (rows + 3) / 4 * ((nw + 7) / 8);
+  return 16LL * nblk_m * 32 * d->Cin * d->Cout;
+}
+
 extern "C" int hands_conv3x3_winograd_f32(const hands_conv_desc* d, const float* in, const float* u_packed, const float* bias,
                                           float* out, hands_stream_t stream) {
   if (!d || !in || !u_packed || !bias || !out || !wino_ok(d)) return HANDS_EINVAL;

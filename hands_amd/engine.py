@@ -51,6 +51,7 @@ class ConvEngine:
                                       # every MFMA launch (conv_igemm and the fused stem) with events; `kernel` is the
                                       # kernel the launch really runs (conv_igemm_f32_kernel / conv_igemm_sk_f32_kernel =
                                       # stream-K / conv_igemm_splitk_f32_kernel = split-K + reduce / stem_pool_*)
+        self.last_wino_macs = 0       # executed (not algorithmic) MACs of the Winograd launch the hook is being called for
         self._splitk_ws = {}          # (device, stream handle) -> workspace tensor
         self._sk_ws = {}              # (device, stream handle) -> [zeroed stream-K workspace, epoch counter]
         self._capture_ws = {}         # split-K workspaces of launches recorded into a hipGraph (graph memory pool)
@@ -137,6 +138,7 @@ class ConvEngine:
         if (self.winograd and pc.wino is not None and res is None and pre is None and S <= 1 and self.math == "fp32"
                 and L.hands_conv3x3_winograd_supported(C.byref(d))):
             if hook is not None:
+                self.last_wino_macs = L.hands_conv3x3_winograd_executed_macs(C.byref(d))   # what the matrix cores execute
                 hook("begin", pc, B * Ho * Wo, stream, False, "conv_wino_f32_kernel")
             check(L.hands_conv3x3_winograd_f32(C.byref(d), ptr(x, x_off), ptr(pc.wino), ptr(pc.bias), ptr(out, out_off), stream),
                   "hands_conv3x3_winograd_f32")

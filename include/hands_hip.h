@@ -92,6 +92,9 @@ int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, const float
  * fp32 rounding only (Winograd re-associates the 3x3 sum).  Requires Cin % 16 == 0, Cout % 32 == 0, act in
  * {NONE, RELU, LEAKY_RELU}; hands_conv3x3_winograd_supported() returns 1 when `d` can take this route. */
 int hands_conv3x3_winograd_supported(const hands_conv_desc* d);
+/* multiply-accumulates the matrix cores execute for the layer on this route (16 per 2x2 output tile and (cin, cout) pair,
+ * idle tile lanes of partial blocks included); 0 if unsupported.  The algorithmic count is 9 * B * H * W * Cin * Cout. */
+long long hands_conv3x3_winograd_executed_macs(const hands_conv_desc* d);
 int hands_conv3x3_winograd_f32(const hands_conv_desc* d, const float* in, const float* u_packed, const float* bias,
                                float* out, hands_stream_t stream);
 

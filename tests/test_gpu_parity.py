@@ -721,6 +721,34 @@ def test_forward_vs_golden(golden_dir, gpu_model, bz, seed):
         assert mp < 1e-3, mp          # "MPJPE vs ref" of the north star, mm
 
 
+def test_forward_with_the_direct_3x3_kernel_vs_golden(golden_dir, gpu_model):
+    """engine.winograd = False: the 3x3 / stride-1 layers on the direct implicit GEMM again (the route of rounds 1-2) --
+    same golden bar, and within fp32 re-association noise of the default (Winograd) forward."""
+    d = np.load(os.path.join(golden_dir, "hands_light_bz2_seed1.npz"))
+    inputs, meta = synthetic_inputs(2, 1, device=DEV)
+    meta["is_flipped"] = torch.from_numpy(d["is_flipped"]).to(DEV)
+    seen = []
+    gpu_model.conv_hook = lambda phase, pc, npix, st, has_res, kernel: seen.append(kernel)
+    gpu_model.overlap_trunks = False
+    try:
+        w = {k: v.clone() for k, v in gpu_model(inputs, meta).items()}
+        n_wino = seen.count("conv_wino_f32_kernel")
+        gpu_model.engine.winograd = False
+        seen.clear()
+        o = {k: v.clone() for k, v in gpu_model(inputs, meta).items()}
+        assert n_wino > 0 and n_wino % (2 * 13) == 0 and "conv_wino_f32_kernel" not in seen     # 13 stride-1 3x3 layers per trunk job
+    finally:
+        gpu_model.engine.winograd = True
+        gpu_model.conv_hook = None
+        gpu_model.overlap_trunks = True
+    torch.cuda.synchronize()
+    for hn in "rl":
+        for out in (o, w):
+            verr = np.abs(out[f"mano.vertices.{hn}"].cpu().numpy() - d[f"out/mano.vertices.{hn}"]).max()
+            assert verr < 1e-6, verr
+        assert (o[f"mano.vertices.{hn}"] - w[f"mano.vertices.{hn}"]).abs().max().item() < 1e-6
+
+
 @pytest.mark.parametrize("seed", [0, 2])
 def test_forward_latency_mode_vs_golden(golden_dir, gpu_model, seed):
     """Small-batch serving mode (split-K on every layer with few output tiles): same parity bar."""
