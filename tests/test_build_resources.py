@@ -13,13 +13,19 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-@pytest.mark.parametrize("src", ["conv_igemm.hip", "mano_lbs.hip", "stem_pool.hip"])
+@pytest.mark.parametrize("src", ["conv_igemm.hip", "conv_wino.hip", "mano_lbs.hip", "stem_pool.hip"])
 def test_hot_kernels_do_not_spill(tmp_path, src):
     p = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{ROOT}/hands_amd/csrc",
                         "-fno-fast-math", "-ffp-contract=off", "-Rpass-analysis=kernel-resource-usage", "-c",
-                        os.path.join(ROOT, "hands_amd", "csrc", src), "-o", str(tmp_path / "o.o")],
+                        os.path.join(ROOT, "hands_amd", "csrc", src), "-o", str(tmp_path / "o.o")] +
+                       (["-fno-slp-vectorize"] if src == "conv_wino.hip" else []),      # as hands_amd/csrc/Makefile builds it
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
+    if src == "conv_wino.hip":      # three workgroups per CU: <= 168 registers, <= 53 KB of LDS, accumulators never copied to AGPRs
+        for b in re.split(r"Function Name: ", p.stderr)[1:]:
+            vg, ag = int(re.search(r"VGPRs: (\d+)", b).group(1)), int(re.search(r"AGPRs: (\d+)", b).group(1))
+            lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1))
+            assert vg + ag <= 168 and 40960 < lds <= 54272, (b.split()[0], vg, ag, lds)
     names = re.findall(r"Function Name: (\S+)", p.stderr)
     scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", p.stderr)]
     spills = [int(v) for v in re.findall(r"VGPRs Spill: (\d+)", p.stderr)]
@@ -42,9 +48,11 @@ def test_fp32_conv_kernels_keep_four_workgroups_per_cu(tmp_path):
     seen = 0
     for b in blocks:
         name = b.split()[0]
-        m = re.search(r"conv_igemm_f32_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)E", name)
+        m = re.search(r"conv_igemm_f32_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)E", name)
         if not m or m.group(4) != "0" or m.group(5) != "0":     # plain kernel, PREC 0 (exact fp32), no fused split-K tail
             continue
+        if m.group(6) == "1":      # PRE (BatchNorm -> LeakyReLU on the operand, handoccnet_light's pre-activation units only):
+            continue               # two more staging vectors, 134 VGPRs = 3 workgroups per CU, measured +0.6-1 % over the separate launch
         vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
         agprs = int(re.search(r"AGPRs: (\d+)", b).group(1))
         lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1))
