@@ -46,7 +46,8 @@ struct WinoArgs {
   int nblk_m, nblk_n, nseg;
   int rows;                         // B * nh flattened tile rows
   int nbw, ngrp;                    // channel blocks per workgroup (divides nblk_n), groups = nblk_n / nbw
-  uint32_t nh_mul, nh_sh, ngrp_mul, ngrp_sh, nseg_mul, nseg_sh;   // host-computed magic numbers: x / nh, x / (nblk_n / nbw), x / nseg
+  int sgs;                          // groups per pass of the tile order (divides ngrp): their weights fit an XCD's L2
+  uint32_t nh_mul, nh_sh, sgs_mul, sgs_sh, nbm_mul, nbm_sh, nseg_mul, nseg_sh;   // magic numbers: x / nh, / sgs, / nblk_m, / nseg
 };
 
 // x / d for 0 <= x < 2^31 with M = ceil(2^(31 + l) / d), l = ceil(log2 d) >= 1 (Granlund-Montgomery: exact, M < 2^32);
@@ -116,9 +117,14 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
   const int xi = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = frequency row
   const int l31 = lane & 31, half = lane >> 5;
 
-  const int ngrp = a.ngrp;                                      // channel-block groups per tile block
-  const int tile = wino_xcd_remap(blockIdx.x, a.nblk_m * ngrp);
-  const int mb = fastdiv(tile, a.ngrp_mul, a.ngrp_sh), nb0 = (tile - mb * ngrp) * a.nbw;   // group fastest: one patch, one L2
+  // Tile order (each XCD takes a contiguous eighth of it): passes of `sgs` channel-block groups whose weights (<= 2 MB) stay in
+  // the XCD's 4 MB L2, tile blocks inside a pass, the groups of one patch next to each other.  With all channel blocks in
+  // one pass the 4-17 MB weight sets of the 256- / 512-channel layers were re-streamed from the Infinity Cache by every
+  // workgroup (fabric reads 0.69 / 0.96 GB per launch against 0.10 / 0.03 GB of input).  Any bijection gives the same bits.
+  const int tile = wino_xcd_remap(blockIdx.x, a.nblk_m * a.ngrp);
+  const int tq = fastdiv(tile, a.sgs_mul, a.sgs_sh), gi = tile - tq * a.sgs;
+  const int pass = fastdiv(tq, a.nbm_mul, a.nbm_sh), mb = tq - pass * a.nblk_m;
+  const int nb0 = (pass * a.sgs + gi) * a.nbw;
 
   int R0, s0, tx0;                                              // (all 32-bit: B * nh * nw < 2^31 is checked by the host)
   if constexpr (LINEAR) {
@@ -369,7 +375,15 @@ static int wino_launch(WinoArgs& a, hipStream_t stream) {
   const int ngrp = a.ngrp = a.nblk_n / a.nbw;
   const long long nwg = nblk_m * ngrp;
   wino_magic(a.nh, a.nh_mul, a.nh_sh);
-  wino_magic(ngrp, a.ngrp_mul, a.ngrp_sh);
+  a.sgs = 1;
+  for (int g = 1; g <= ngrp; ++g)                               // largest divisor of ngrp whose weights are <= 2 MB
+    if (ngrp % g == 0 && (long long)g * a.nbw * 2048 * a.Cin <= (2LL << 20)) a.sgs = g;
+  if (const char* e = getenv("HANDS_WINO_SGS")) {               // developer override (must divide the group count)
+    const int g = atoi(e);
+    if (g >= 1 && ngrp % g == 0) a.sgs = g;
+  }
+  wino_magic(a.sgs, a.sgs_mul, a.sgs_sh);
+  wino_magic(a.nblk_m, a.nbm_mul, a.nbm_sh);
   wino_magic(a.nseg, a.nseg_mul, a.nseg_sh);
   // 32-bit byte offsets from the first image a block touches
   const long long imgs = G::NR / a.nh + 2;
@@ -410,7 +424,7 @@ extern "C" int hands_conv3x3_winograd_f32(const hands_conv_desc* d, const float*
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.act = d->act & HANDS_ACT_MASK;
   if ((long long)d->B * a.nh >= 0x7fffff00LL) return HANDS_EINVAL;
   a.rows = d->B * a.nh;
-  a.nblk_m = a.nblk_n = a.nseg = a.nbw = a.ngrp = 0;
+  a.nblk_m = a.nblk_n = a.nseg = a.nbw = a.ngrp = a.sgs = 0;
   hipStream_t s = (hipStream_t)stream;
   if (a.nw == 7) return wino_launch<7, true>(a, s);
   if (a.nw % 4 == 0 || a.nw < 8) return wino_launch<4, false>(a, s);
