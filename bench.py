@@ -295,6 +295,9 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         model.engine.winograd = bool(winograd)
     if os.environ.get("HANDS_WINOGRAD"):           # developer A/B switch
         model.engine.winograd = os.environ["HANDS_WINOGRAD"] == "1"
+    if os.environ.get("HANDS_WINOGRAD_SCOPE") and hasattr(model, "winograd_scope"):   # developer A/B switch: all | trunk
+        model.winograd_scope = os.environ["HANDS_WINOGRAD_SCOPE"]
+        model.invalidate_packed()
     if os.environ.get("HANDS_FUSE_LINK"):          # developer A/B switch
         model.engine.fuse_link = os.environ["HANDS_FUSE_LINK"] == "1"
     if os.environ.get("HANDS_ASYNC_FORWARD") and hasattr(model, "async_forward"):      # developer A/B switch

@@ -88,6 +88,10 @@ class HandOccNet(EngineSwitches, nn.Module):
         # network amplifies any fp32 re-association (DESIGN.md "Conditioning note"): with it one of the two golden seeds
         # lands 1.07e-6 m from the reference's own fp32 output (bar 1e-6 m; direct kernel 5.3e-7 m)
         self.engine.winograd = False
+        self.winograd_scope = "all"    # which 3x3 / stride-1 layers get Winograd weights at pack time: "all" | "trunk" (the
+                                       # ResNet-50 trunk only: FPN smoothing, FIT convolutions and the regressor's units stay
+                                       # on the direct kernel) -- only read when engine.winograd is on; call invalidate_packed()
+                                       # after changing it
         self.small_map_splitk = True   # call-site constant split-K on maps of <= 8x8 pixels (see _conv_fns)
         self.chunks = 2   # the 2*bz crops run as this many jobs on separate HIP streams (1 = single stream)
         self.async_forward = True   # two forwards in flight: call i runs on pipeline stream i & 1 and is joined at the first
@@ -129,7 +133,8 @@ class HandOccNet(EngineSwitches, nn.Module):
             if bn is not None:
                 s, t = bn_affine(bn)
                 w, b = w * s.view(-1, 1, 1, 1), b * s + t
-            return pack_conv(w, b, stride, pad, dev, cin_pad_to=cin_pad_to)
+            wino = self.winograd_scope == "all" or (self.winograd_scope == "trunk" and p.startswith("backbone.layer"))
+            return pack_conv(w, b, stride, pad, dev, cin_pad_to=cin_pad_to, winograd=wino)
 
         def lin(p, **kw):
             return pack_linear(sd[p + ".weight"], sd[p + ".bias"], dev, **kw)

@@ -31,16 +31,22 @@ for seed in range(n):
     except Exception as e:      # the oracle may not be dtype-generic everywhere
         ref64 = None
     row = []
-    for wino in (False, True):
-        model.engine.winograd = wino
+    for wino in (False, True, "trunk"):
+        model.engine.winograd = bool(wino)
+        scope = "trunk" if wino == "trunk" else "all"
+        if model.winograd_scope != scope:
+            model.winograd_scope = scope
+            model.invalidate_packed()
         out = model({k: v.to("cuda") for k, v in ci.items()}, {k: v.to("cuda") for k, v in cm.items()})
         torch.cuda.synchronize()
         e32 = max((out[f"mano.vertices.{h}"].cpu() - ref32[f"mano.vertices.{h}"]).abs().max().item() for h in "rl")
         e64 = max((out[f"mano.vertices.{h}"].cpu().double() - ref64[f"mano.vertices.{h}"]).abs().max().item() for h in "rl") if ref64 else float("nan")
         row += [e32, e64]
-        for key, v in ((("wino" if wino else "direct") + " vs ref fp32", e32), (("wino" if wino else "direct") + " vs fp64", e64)):
+        nm = {False: "direct", True: "wino", "trunk": "wino-trunk"}[wino]
+        for key, v in ((nm + " vs ref fp32", e32), (nm + " vs fp64", e64)):
             worst[key] = max(worst.get(key, 0.0), v)
     r64 = max((ref32[f"mano.vertices.{h}"].double() - ref64[f"mano.vertices.{h}"]).abs().max().item() for h in "rl") if ref64 else float("nan")
     worst["ref fp32 vs fp64"] = max(worst.get("ref fp32 vs fp64", 0.0), r64)
-    print(f"seed {seed}: direct vs ref32 {row[0]:.2e} vs fp64 {row[1]:.2e} | wino vs ref32 {row[2]:.2e} vs fp64 {row[3]:.2e} | ref32 vs fp64 {r64:.2e}")
+    print(f"seed {seed}: direct vs ref32 {row[0]:.2e} vs fp64 {row[1]:.2e} | wino vs ref32 {row[2]:.2e} vs fp64 {row[3]:.2e} | "
+          f"wino-trunk vs ref32 {row[4]:.2e} vs fp64 {row[5]:.2e} | ref32 vs fp64 {r64:.2e}")
 print("worst over seeds:", {k: f"{v:.2e}" for k, v in worst.items()})
