@@ -110,6 +110,32 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const float* __restrict__ 
       __syncthreads();
     }
   } else
+  if (VARIANT == 12) {
+    // weights straight from L2 in MFMA operand order (W is read as if packed [n / 32][k16][kk][lane 64][4]: 1 KB per wave
+    // instruction), one k-step ahead in registers; only the activations go through LDS
+    float4 wq[2][2][2];
+    const float* wbase = W + ((size_t)(n0 / 32 + wn * 2) * nk) * 512 + lane * 4;
+#define LOADW12(SET, kt) { for (int i = 0; i < 2; ++i) for (int kk = 0; kk < 2; ++kk) wq[SET][i][kk] = *(const float4*)(wbase + ((size_t)i * nk + (kt)) * 512 + kk * 256); }
+#define LOADX12(kt) { xr0 = *(const float4*)(xp0 + (kt) * BK); xr1 = *(const float4*)(xp1 + (kt) * BK); }
+#define STOREX12(buf) { float* dx = sX + (buf) * BM * LR + srow * LR + chunk * 4; *(float4*)dx = xr0; *(float4*)(dx + 64 * LR) = xr1; }
+#define STEP12(SET, buf) { \
+      for (int kk = 0; kk < 2; ++kk) for (int i = 0; i < 2; ++i) xf[i][kk] = *(const float4*)(fx + (buf) * BM * LR + i * 32 * LR + kk * 8); \
+      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int t = 0; t < 4; ++t) _Pragma("unroll") for (int i = 0; i < 2; ++i) \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(wq[SET][i][kk], t), f4e(xf[j][kk], t), acc[i][j], 0, 0, 0); }
+    LOADW12(0, 0);
+    for (int kt = 0; kt + 1 < nk; kt += 2) {
+      LOADX12(kt + 1); LOADW12(1, kt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      STEP12(0, 0);
+      STOREX12(1);
+      __syncthreads();
+      { const int k2 = kt + 2 < nk ? kt + 2 : kt; LOADX12(k2); LOADW12(0, k2); }
+      __builtin_amdgcn_sched_barrier(0);
+      STEP12(1, 1);
+      STOREX12(0);
+      __syncthreads();
+    }
+  } else
   if (VARIANT == 5) {
     LOADT(1);
     for (int kt = 0; kt < nk - 1; ++kt) {
@@ -291,6 +317,7 @@ int main(int argc, char** argv) {
     run<9>(X, W, D, M, N, K, "9 ds_write, no global loads");
     run<6>(X, W, D, M, N, K, "6 global_load_lds direct");
     run<7>(X, W, D, M, N, K, "7 global_load_lds asm, own waits");
+    run<12>(X, W, D, M, N, K, "12 W operand-ordered from L2, X via LDS");
   }
   for (int var = 6; var <= 7; ++var) {  // spot-check variants 6, 7 against a host dot product
     hipMemset(D, 0, (size_t)M * N * 4);
