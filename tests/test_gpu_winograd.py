@@ -142,3 +142,31 @@ def test_winograd_rejects_what_it_cannot_run():
         d = ConvDesc(2, 14, 14, 64, 14, 14, 64, 3, 3, 1, 1, 64, 64, 0, 576, 1)
         setattr(d, field, val)
         assert L.hands_conv3x3_winograd_supported(C.byref(d)) == 0, field
+
+
+@pytest.mark.parametrize("shape", [(512, 64, 56), (512, 128, 28), (512, 256, 14), (256, 512, 7)])
+def test_winograd_full_size_against_the_direct_kernel(shape):
+    """BASELINE configs[1] sizes (the launches of a bz = 256 forward: 512 hand crops / 256 images per trunk job): EVERY
+    output of the Winograd launch against the direct implicit-GEMM kernel on the same device tensors (the direct kernel is
+    pinned to fp64 convolutions by tests/test_gpu_parity.py), plus linearity in the input -- a size-independent property."""
+    B, Cch, H = shape
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(B + Cch)
+    w = torch.randn(Cch, Cch, 3, 3, generator=g) / (Cch * 9) ** 0.5
+    bias = torch.randn(Cch, generator=g)
+    pc = pack_conv(w, bias, 1, 1, DEV)
+    gd = torch.Generator(device=DEV).manual_seed(1)
+    x1 = torch.randn(B, H, H, Cch, device=DEV, generator=gd)
+    x2 = torch.randn(B, H, H, Cch, device=DEV, generator=gd)
+    wino, direct = ConvEngine(), ConvEngine()
+    direct.winograd = False
+    run = lambda eng, x, act: (lambda o: (eng.conv(L, pc, x, B, H, H, o, act, _stream()), o)[1])(torch.empty(B, H, H, Cch, device=DEV))
+    yw, yd = run(wino, x1, 1), run(direct, x1, 1)
+    torch.cuda.synchronize()
+    scale = yd.abs().max().item()
+    assert (yw - yd).abs().max().item() <= 2e-5 * scale
+    # linearity (activation off): conv(x1 + x2) + bias = conv(x1) + conv(x2)  [each side carries the bias once / twice]
+    y1, y2, y12 = run(wino, x1, 0), run(wino, x2, 0), run(wino, x1 + x2, 0)
+    torch.cuda.synchronize()
+    b = pc.bias[:Cch].view(1, 1, 1, Cch)
+    assert (y12 + b - y1 - y2).abs().max().item() <= 3e-5 * y12.abs().max().item()
