@@ -298,6 +298,8 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
     if os.environ.get("HANDS_WINOGRAD_SCOPE") and hasattr(model, "winograd_scope"):   # developer A/B switch: all | trunk
         model.winograd_scope = os.environ["HANDS_WINOGRAD_SCOPE"]
         model.invalidate_packed()
+    if os.environ.get("HANDS_FUSE_EXPAND"):        # developer A/B switch (default: on)
+        model.engine.fuse_expand = os.environ["HANDS_FUSE_EXPAND"] == "1"
     if os.environ.get("HANDS_FUSE_LINK"):          # developer A/B switch
         model.engine.fuse_link = os.environ["HANDS_FUSE_LINK"] == "1"
     if os.environ.get("HANDS_ASYNC_FORWARD") and hasattr(model, "async_forward"):      # developer A/B switch
@@ -364,7 +366,7 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
             else:
                 nbytes = 4.0 * (npix * pc.Cout * (2 if has_res else 1) + npix * pc.stride * pc.stride * pc.Cin + pc.w.numel())
             # Winograd launches execute 16 / 36 of the layer's algorithmic multiplications (+ idle tile lanes): keep both counts
-            xmacs = model.engine.last_wino_macs if kernel == "conv_wino_f32_kernel" else macs
+            xmacs = model.engine.last_wino_macs if kernel.startswith("conv_wino") else macs
             info.append((kernel, pc.Cin, pc.Cout, pc.KH, pc.stride, npix, macs, nbytes, xmacs))
 
     n_prof = 2
@@ -681,7 +683,8 @@ def main():
                                       ("torchrun" if ctx.world > 1 else "direct"),
                        "timed_mode": "serial (one HIP stream)" if args.serial else "multi-stream (shipped default)",
                        "latency_mode": bool(args.latency_mode),
-                       "conv3x3_stride1": ("winograd_f2x2_3x3 on fp32 MFMA (hands_conv3x3_winograd_f32)" if model.engine.winograd
+                       "conv3x3_stride1": (None if model is None or not hasattr(model, "engine") else
+                                           "winograd_f2x2_3x3 on fp32 MFMA (hands_conv3x3_winograd_f32)" if model.engine.winograd
                                            else "direct implicit GEMM (hands_conv2d_nhwc_f32)")},
             "hands_per_sec_per_gpu": res["hands_per_sec_per_gpu"],
             "roofline": res["roofline"], "cpu_baseline": cpu_baseline, "parity": parity,

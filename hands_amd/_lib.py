@@ -59,6 +59,8 @@ SIGNATURES = {
     "hands_conv2d_nhwc_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P],
     "hands_conv3x3_winograd_supported": [C.POINTER(ConvDesc)],
     "hands_conv3x3_winograd_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
+    "hands_bottleneck_wino_expand_supported": [C.POINTER(ConvDesc), _I],
+    "hands_bottleneck_wino_expand_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P],
     "hands_bottleneck_link_f32": [_P, _P, _P, _P, _P, _P, _P, _P, C.c_longlong, _I, _P],
     "hands_conv2d_splitk_factor": [C.POINTER(ConvDesc)],
     "hands_conv2d_nhwc_splitk_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_longlong, _P],
@@ -115,6 +117,7 @@ SIGNATURES = {
     "hands_pack_conv1x1_dual_f64": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
     "hands_pack_mano_f32": [_P] * 10,
     "hands_pack_conv3x3_winograd_f64": [_I, _I, _P, _P],
+    "hands_pack_conv1x1_operand_f32": [_I, _I, _I, _P, _P],
 }
 EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string", "hands_conv2d_workspace_floats", "hands_pack_conv3x3_winograd_floats", "hands_conv3x3_winograd_executed_macs",
                  "hands_conv2d_streamk_workspace_bytes", "hands_stream_is_capturing")

@@ -46,6 +46,13 @@ struct WinoArgs {
   int nblk_m, nblk_n, nseg;
   int rows;                         // B * nh flattened tile rows
   int nbw, ngrp;                    // channel blocks per workgroup (divides nblk_n), groups = nblk_n / nbw
+  // EXPAND kernels (hands_bottleneck_wino_expand_f32): the block's conv3 (1x1, Cmid -> Cout3) + bn3 + identity + ReLU on the
+  // 128 pixels this workgroup has just produced, while they are still in the XCD's L2
+  const float* __restrict__ w3;     // [Cout3 / 32][Cmid / 8][lane 64][4]  (hands_pack_conv1x1_operand_f32)
+  const float* __restrict__ bias3;
+  const float* ident;               // (B, H, W, Cout3) residual, pixel stride id_ps
+  float* out3;                      // (B, H, W, Cout3), pixel stride out3_ps
+  int Cout3, id_ps, out3_ps;
   int sgs;                          // groups per pass of the tile order (divides ngrp): their weights fit an XCD's L2
   uint32_t nh_mul, nh_sh, sgs_mul, sgs_sh, nbm_mul, nbm_sh, nseg_mul, nseg_sh;   // magic numbers: x / nh, / sgs, / nblk_m, / nseg
 };
@@ -104,7 +111,7 @@ constexpr int ZROUND_FLOATS = 4 * 32 * 32;                      // epilogue exch
 // One workgroup: 32 tiles (128 output pixels) x `nbw` blocks of 32 output channels, one after the other on the same
 // patch (the tile setup and the first fill's latency are paid once; the stages of consecutive channel blocks form one
 // software pipeline).
-template <int D, bool LINEAR>
+template <int D, bool LINEAR, int XCM = 0>      // XCM > 0: + the bottleneck's 1x1 expand convolution over XCM = Cout channels
 __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs a) {
   using G = WinoGeom<D, LINEAR>;
   // (at least 41 KB: 3 workgroups per CU is what the ~150 registers allow anyway, and hipcc then schedules for that)
@@ -317,6 +324,95 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
 #undef WINO_STEP
 #undef WINO_LOADW
 #undef WINO_FILL
+
+  if constexpr (XCM > 0) {
+    // ---- conv3 of the bottleneck on this workgroup's 128 pixels (resnet.py:146-154): out3 = relu(W3 . t2 + b3 + identity).
+    //      t2 = what the stages above have just stored (all XCM channels: nbw = all channel blocks); it is read back from L2
+    //      (sc1 loads: this CU's L1 is bypassed) as the MFMA B operand, W3 arrives in operand order like the Winograd weights,
+    //      and the k order (8 kk + t, 8 kk + 4 + t) and the epilogue ((acc + bias) + identity, max 0) are conv_igemm's: the
+    //      same bits as the separate hands_conv2d_nhwc_f32 launch.  Identity reads and output writes of this phase overlap the
+    //      stages of the CU's other workgroups -- as separate launches they are an HBM-bound kernel of their own (77 TFLOP/s).
+    static_assert(XCM % 8 == 0 && XCM <= 64, "B and A fragments of the expand phase live in registers");
+    constexpr int NKK = XCM / 8;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's t2 stores have reached the L2
+    __syncthreads();
+    // this lane's pixel as MFMA column: tile 8 xi + (l31 >> 2), output pixel (i, j) = ((l31 >> 1) & 1, l31 & 1)
+    auto pix_off = [&](int tl_, int i_, int j_, int ps) -> int {   // float offset from the block's first image, -1: no such pixel
+      const int q = s0 + tl_;
+      const int Rq = q / D, cq_ = q - Rq * D;
+      const int t = ty_first + Rq;
+      const int db = fastdiv(t, a.nh_mul, a.nh_sh), ty = t - db * a.nh;
+      const int oy = 2 * ty + i_, ox = 2 * (tx0 + cq_) + j_;
+      const bool ok = R0 + Rq < a.rows && tx0 + cq_ < a.nw && oy < a.H && ox < a.W;
+      return ok ? ((db * a.H + oy) * a.W + ox) * ps : -1;
+    };
+    const size_t img0 = (size_t)b_first * a.H * a.W;
+    const __amdgpu_buffer_rsrc_t t2_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + img0 * a.out_ps, 0, (int)0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w3), 0, (int)0x80000000u, 0x00020000);
+    const int bpo = pix_off(8 * xi + (l31 >> 2), (l31 >> 1) & 1, l31 & 1, a.out_ps);
+    float4 bq[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk)
+      bq[kk] = f4(__builtin_amdgcn_raw_buffer_load_b128(t2_rsrc, bpo >= 0 ? (bpo + 8 * kk + 4 * half) * 4 : (int)0x80000000u, 0, 17));
+    // epilogue rows: pass p handles pixel 8 p + (lane >> 3) of the wave's 32, 16-byte quad lane & 7 of the 32-channel block
+    int eo_id[4], eo_out[4];
+#pragma unroll
+    for (int p4 = 0; p4 < 4; ++p4) {
+      const int n = 8 * p4 + (lane >> 3);
+      eo_id[p4] = pix_off(8 * xi + (n >> 2), (n >> 1) & 1, n & 1, a.id_ps);
+      eo_out[p4] = pix_off(8 * xi + (n >> 2), (n >> 1) & 1, n & 1, a.out3_ps);
+    }
+    const float* idp = a.ident + img0 * a.id_ps + (lane & 7) * 4;
+    float* outp = a.out3 + img0 * a.out3_ps + (lane & 7) * 4;
+    float* sE = lds + xi * 1024;                               // this wave's 32 x 32 transposition tile (rows of 8 quads, swizzled)
+    const int nb3n = a.Cout3 >> 5;
+    // One weight register set, re-loaded fragment by fragment for the next channel block right after its four MFMAs (a whole
+    // block of cover); the identity rows are requested TWO blocks ahead into a ring of three register sets: an HBM read takes
+    // several microseconds under load, a block's 32 MFMAs take one.
+    float4 aq[NKK], idv[3][4];
+#define WINO_LOADID(SET, NB3)                                                                      \
+    do {                                                                                            \
+      _Pragma("unroll") for (int p4 = 0; p4 < 4; ++p4)                                              \
+        idv[SET][p4] = (eo_id[p4] >= 0 && (NB3) < nb3n) ? *reinterpret_cast<const float4*>(idp + eo_id[p4] + (NB3) * 32) \
+                                                        : make_float4(0.f, 0.f, 0.f, 0.f);          \
+    } while (0)
+#define WINO_EXPAND(SET, NB3)                                                                      \
+    do {                                                                                            \
+      WINO_LOADID((SET + 2) % 3, (NB3) + 2);                                                        \
+      const int nxt = (NB3) + 1 < nb3n ? (NB3) + 1 : (NB3);                                         \
+      f32x16 c3;                                                                                    \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) c3[r] = 0.f;                                   \
+      _Pragma("unroll") for (int kk = 0; kk < NKK; ++kk) {                                          \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                               \
+          c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(aq[kk], t), f4e(bq[kk], t), c3, 0, 0, 0);   \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        aq[kk] = f4(__builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, lane * 16 + kk * 1024, nxt * (NKK * 1024), 0)); \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+      }                                                                                             \
+      const float4 b3 = *reinterpret_cast<const float4*>(a.bias3 + (NB3) * 32 + (lane & 7) * 4);     \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g)      /* channel quad 2 g + half of pixel l31 */  \
+        *reinterpret_cast<float4*>(sE + (l31 * 8 + ((2 * g + half) ^ (l31 & 7))) * 4) =              \
+            make_float4(c3[4 * g + 0], c3[4 * g + 1], c3[4 * g + 2], c3[4 * g + 3]);                \
+      _Pragma("unroll") for (int p4 = 0; p4 < 4; ++p4) {                                            \
+        const int n = 8 * p4 + (lane >> 3);                                                         \
+        const float4 c = *reinterpret_cast<const float4*>(sE + (n * 8 + ((lane & 7) ^ (n & 7))) * 4); \
+        float4 y = add4(add4(c, b3), idv[SET][p4]);                                                 \
+        y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);  \
+        if (eo_out[p4] >= 0) *reinterpret_cast<float4*>(outp + eo_out[p4] + (NB3) * 32) = y;        \
+      }                                                                                             \
+    } while (0)
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) aq[kk] = f4(__builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, lane * 16 + kk * 1024, 0, 0));
+    WINO_LOADID(0, 0);
+    WINO_LOADID(1, 1);
+    for (int nb3 = 0; nb3 < nb3n; nb3 += 3) {
+      WINO_EXPAND(0, nb3);
+      if (nb3 + 1 < nb3n) WINO_EXPAND(1, nb3 + 1);
+      if (nb3 + 2 < nb3n) WINO_EXPAND(2, nb3 + 2);
+    }
+#undef WINO_LOADID
+#undef WINO_EXPAND
+  }
 }
 
 }  // namespace
@@ -338,7 +434,7 @@ static void wino_magic(int d, uint32_t& mul, uint32_t& sh) {
   sh = (uint32_t)(l - 1);                                       // (x * mul) >> (31 + l) = umulhi(x, mul) >> (l - 1)
 }
 
-template <int D, bool LINEAR>
+template <int D, bool LINEAR, int XCM = 0>
 static int wino_launch(WinoArgs& a, hipStream_t stream) {
   using G = WinoGeom<D, LINEAR>;
   const long long rows = a.rows;
@@ -372,6 +468,7 @@ static int wino_launch(WinoArgs& a, hipStream_t stream) {
     const int w = atoi(e);
     if (w >= 1 && a.nblk_n % w == 0) a.nbw = w;
   }
+  if (XCM > 0) a.nbw = a.nblk_n;                                // the expand phase needs all channels of its 128 pixels
   const int ngrp = a.ngrp = a.nblk_n / a.nbw;
   const long long nwg = nblk_m * ngrp;
   wino_magic(a.nh, a.nh_mul, a.nh_sh);
@@ -388,7 +485,10 @@ static int wino_launch(WinoArgs& a, hipStream_t stream) {
   // 32-bit byte offsets from the first image a block touches
   const long long imgs = G::NR / a.nh + 2;
   if (imgs * a.H * a.W * a.in_ps * 4 >= 0x7fffffffLL) return HANDS_EINVAL;
-  hipLaunchKernelGGL((conv_wino_f32_kernel<D, LINEAR>), dim3((unsigned)nwg), dim3(256), 0, stream, a);
+  if (XCM > 0 && imgs * a.H * a.W * (long long)(a.out_ps > a.id_ps ? (a.out_ps > a.out3_ps ? a.out_ps : a.out3_ps)
+                                                                     : (a.id_ps > a.out3_ps ? a.id_ps : a.out3_ps)) * 4 >= 0x7fffffffLL)
+    return HANDS_EINVAL;
+  hipLaunchKernelGGL((conv_wino_f32_kernel<D, LINEAR, XCM>), dim3((unsigned)nwg), dim3(256), 0, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -425,8 +525,41 @@ extern "C" int hands_conv3x3_winograd_f32(const hands_conv_desc* d, const float*
   if ((long long)d->B * a.nh >= 0x7fffff00LL) return HANDS_EINVAL;
   a.rows = d->B * a.nh;
   a.nblk_m = a.nblk_n = a.nseg = a.nbw = a.ngrp = a.sgs = 0;
+  a.w3 = a.bias3 = a.ident = nullptr; a.out3 = nullptr; a.Cout3 = a.id_ps = a.out3_ps = 0;
   hipStream_t s = (hipStream_t)stream;
   if (a.nw == 7) return wino_launch<7, true>(a, s);
   if (a.nw % 4 == 0 || a.nw < 8) return wino_launch<4, false>(a, s);
   return wino_launch<8, false>(a, s);
+}
+
+// conv2 (3x3, Winograd) + bn2 + relu  ->  conv3 (1x1 expand) + bn3 + identity + relu of a stride-1 Bottleneck without a
+// downsample branch (src/nets/backbone/resnet.py:140-154) in ONE launch.  `d` describes conv2 exactly as for
+// hands_conv3x3_winograd_f32 (d->Cout = planes = 64, act = RELU); t2 (B, H, W, planes) is still written (the block's
+// conv2 output, pixel stride d->out_pix_stride) and read back from L2 by the workgroup that produced it.
+// Same bits as hands_conv3x3_winograd_f32 followed by hands_conv2d_nhwc_f32(conv3, residual = identity, RELU).
+extern "C" int hands_bottleneck_wino_expand_supported(const hands_conv_desc* d, int Cout3) {
+  return d && wino_ok(d) && d->Cout == 64 && (d->act & HANDS_ACT_MASK) == HANDS_ACT_RELU && Cout3 >= 32 && Cout3 % 32 == 0 ? 1 : 0;
+}
+
+extern "C" int hands_bottleneck_wino_expand_f32(const hands_conv_desc* d, const float* in, const float* u_packed, const float* bias2,
+                                                float* t2, const float* w3_operand, const float* bias3, int Cout3,
+                                                const float* identity, int id_pix_stride, float* out, int out_pix_stride,
+                                                hands_stream_t stream) {
+  if (!d || !in || !u_packed || !bias2 || !t2 || !w3_operand || !bias3 || !identity || !out ||
+      !hands_bottleneck_wino_expand_supported(d, Cout3) || id_pix_stride < Cout3 || out_pix_stride < Cout3 ||
+      id_pix_stride % 4 || out_pix_stride % 4)
+    return HANDS_EINVAL;
+  WinoArgs a;
+  a.in = in; a.u = u_packed; a.bias = bias2; a.out = t2;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
+  a.nh = (d->H + 1) / 2; a.nw = (d->W + 1) / 2;
+  a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.act = HANDS_ACT_RELU;
+  if ((long long)d->B * a.nh >= 0x7fffff00LL) return HANDS_EINVAL;
+  a.rows = d->B * a.nh;
+  a.nblk_m = a.nblk_n = a.nseg = a.nbw = a.ngrp = a.sgs = 0;
+  a.w3 = w3_operand; a.bias3 = bias3; a.ident = identity; a.out3 = out; a.Cout3 = Cout3; a.id_ps = id_pix_stride; a.out3_ps = out_pix_stride;
+  hipStream_t s = (hipStream_t)stream;
+  if (a.nw == 7) return wino_launch<7, true, 64>(a, s);
+  if (a.nw % 4 == 0 || a.nw < 8) return wino_launch<4, false, 64>(a, s);
+  return wino_launch<8, false, 64>(a, s);
 }

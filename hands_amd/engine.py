@@ -38,6 +38,14 @@ class ConvEngine:
         self.winograd = True          # 3x3 / stride 1 / pad 1 layers as Winograd F(2x2,3x3) on the fp32 matrix cores
                                       # (hands_conv3x3_winograd_f32: 2.25x fewer multiplications; fp32 throughout, results
                                       # differ from the direct kernel by fp32 rounding).  False = the direct implicit GEMM
+        self.fuse_expand = False      # stride-1 bottlenecks with 64 planes and no downsample branch (layer1): conv2 (Winograd) and
+                                      # conv3 + identity + ReLU as ONE launch (hands_bottleneck_wino_expand_f32): the workgroup that
+                                      # produced 128 pixels of t2 runs conv3 on them (t2 read back from L2, identity rows requested
+                                      # two channel blocks ahead).  Bit-identical to the two launches; measured NEUTRAL (round 3:
+                                      # 1.30-1.39 ms against 1.27-1.30 ms per 512-image bottleneck half, forward 11.40 k hands/s
+                                      # either way): the expand phase is HBM-bound at its share of the bus (60 k of a workgroup's
+                                      # 156 k cycles) and slows the Winograd stages of its neighbours (9.4 k instead of 6.8 k
+                                      # cycles per stage) by what it saves.  Opt-in, kept as the tested reference of the fusion.
         self.fuse_mano = True         # MANOHead.forward of both hands as one launch (hands_mano_heads_f32)
         self.fuse_pre = True          # handoccnet_light's pre-activation units: BatchNorm -> LeakyReLU folded into the operand
                                       # staging of the unit's first (pointwise) convolution (hands_conv2d_nhwc_pre_f32)
@@ -64,7 +72,7 @@ class ConvEngine:
 
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
-        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "winograd", "fuse_mano", "fuse_pre", "fuse_link", "fuse_splitk_reduce", "stream_k", "math"):
+        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "winograd", "fuse_expand", "fuse_mano", "fuse_pre", "fuse_link", "fuse_splitk_reduce", "stream_k", "math"):
             setattr(e, k, getattr(self, k))
         return e
 
@@ -188,6 +196,27 @@ class ConvEngine:
             hook("end", pc, B * Ho * Wo, stream, res is not None, kname)
         return Ho, Wo
 
+    def expand_ok(self, L, c2, c3, B, H, W):
+        """Can conv2 (3x3 / stride 1) + conv3 (1x1 expand, + identity, ReLU) of one bottleneck run as one launch?"""
+        if not (self.winograd and self.fuse_expand and self.math == "fp32" and c2.wino is not None and c3.w_op is not None
+                and c3.KH == 1 and c3.stride == 1 and c3.pad == 0 and c3.Cin == c2.Cout):
+            return False
+        d = ConvDesc(B, H, W, c2.Cin, H, W, c2.Cout, 3, 3, 1, 1, c2.Cin, c2.Cout, 0, c2.Kpad, 1)
+        return bool(L.hands_bottleneck_wino_expand_supported(C.byref(d), c3.Cout))
+
+    def bottleneck_wino_expand(self, L, c2, c3, t1, t2, ident, out, B, H, W, stream, out_off=0):
+        """t2 = relu(conv2(t1)), out = relu(conv3(t2) + identity) in one launch (resnet.py:140-154)."""
+        d = ConvDesc(B, H, W, c2.Cin, H, W, c2.Cout, 3, 3, 1, 1, c2.Cin, c2.Cout, 0, c2.Kpad, 1)
+        hook = self.hook
+        if hook is not None:
+            self.last_wino_macs = L.hands_conv3x3_winograd_executed_macs(C.byref(d)) + c3.macs_per_pixel * B * H * W
+            hook("begin", _ExpandPC(c2, c3), B * H * W, stream, True, "conv_wino_expand_f32_kernel")
+        check(L.hands_bottleneck_wino_expand_f32(C.byref(d), ptr(t1), ptr(c2.wino), ptr(c2.bias), ptr(t2), ptr(c3.w_op), ptr(c3.bias),
+                                                 c3.Cout, ptr(ident), c3.Cout, ptr(out, out_off), c3.Cout, stream),
+              "hands_bottleneck_wino_expand_f32")
+        if hook is not None:
+            hook("end", _ExpandPC(c2, c3), B * H * W, stream, True, "conv_wino_expand_f32_kernel")
+
     def conv_dual(self, L, pc, split, x, x2, B, Ho, Wo, H2, W2, out, stream, act=1, out_off=0):
         """act(conv3(x) + downsample(x2)) (resnet.py:146-154) with the identity never materialised."""
         K0, K1, stride2 = split
@@ -254,6 +283,17 @@ class _LinkPC:
         # bytes per pixel: t2 in, identity in, out, t1 out (+ both weight matrices once per launch)
         self.alg_bytes_per_pixel = 4.0 * (c3.Cin + 2 * c3.Cout + c1.Cout)
         self.w = _Numel(c3.w.numel() + c1.w.numel())
+
+
+class _ExpandPC:
+    """What bench.py's launch hook reads for the fused conv2 (Winograd) + conv3 launch: algorithmic work of BOTH layers."""
+
+    def __init__(self, c2, c3):
+        self.Cin, self.Cout, self.KH, self.KW, self.stride = c2.Cin, c3.Cout, 3, 3, 1
+        self.macs_per_pixel = c2.macs_per_pixel + c3.macs_per_pixel
+        # bytes per pixel: t1 in, t2 out (still written), identity in, out (+ both weight sets once per launch)
+        self.alg_bytes_per_pixel = 4.0 * (c2.Cin + c2.Cout + 2 * c3.Cout)
+        self.w = _Numel(c2.wino.numel() + c3.w.numel())
 
 
 class _Numel:

@@ -721,6 +721,31 @@ def test_forward_vs_golden(golden_dir, gpu_model, bz, seed):
         assert mp < 1e-3, mp          # "MPJPE vs ref" of the north star, mm
 
 
+def test_forward_with_and_without_the_fused_expand_is_bit_identical(gpu_model):
+    """engine.fuse_expand (layer1's conv2 + conv3 as hands_bottleneck_wino_expand_f32) changes launches, not bits."""
+    inputs, meta = synthetic_inputs(3, 5, device=DEV)
+    seen = []
+    gpu_model.conv_hook = lambda phase, pc, npix, st, has_res, kernel: seen.append(kernel)
+    gpu_model.overlap_trunks = False
+    try:
+        assert gpu_model.engine.fuse_expand is False                # opt-in (measured neutral)
+        gpu_model.engine.fuse_expand = True
+        a = {k: v.clone() for k, v in gpu_model(inputs, meta).items()}
+        n_fused = seen.count("conv_wino_expand_f32_kernel")
+        gpu_model.engine.fuse_expand = False
+        seen.clear()
+        b = {k: v.clone() for k, v in gpu_model(inputs, meta).items()}
+        assert n_fused > 0 and n_fused % 4 == 0 and "conv_wino_expand_f32_kernel" not in seen    # 2 blocks of layer1 per trunk job
+    finally:
+        gpu_model.engine.fuse_expand = False
+        gpu_model.conv_hook = None
+        gpu_model.overlap_trunks = True
+    torch.cuda.synchronize()
+    assert sorted(a) == sorted(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_forward_with_the_direct_3x3_kernel_vs_golden(golden_dir, gpu_model):
     """engine.winograd = False: the 3x3 / stride-1 layers on the direct implicit GEMM again (the route of rounds 1-2) --
     same golden bar, and within fp32 re-association noise of the default (Winograd) forward."""

@@ -160,6 +160,10 @@ typedef float f32x16""", "globals")
     s = sub(s, "    ++nbi;\n  }\n", "    ++nbi;\n    __builtin_amdgcn_sched_barrier(0); epi_t += __builtin_amdgcn_s_memtime() - epi_0; "
             "__builtin_amdgcn_sched_barrier(0);\n  }\n  " + st % 5 +
             "\n  if (threadIdx.x == 0 && blockIdx.x < 32768) g_wprof[blockIdx.x * 8 + 4] = epi_t;\n", "exit")
+    # expand phase (fused conv3): slot 6 = its start (after the barrier), slot 7 = its end
+    s = sub(s, "    constexpr int NKK = XCM / 8;\n    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");          // this wave's t2 stores have reached the L2\n    __syncthreads();\n",
+            "    constexpr int NKK = XCM / 8;\n    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    __syncthreads();\n    " + st % 6 + "\n", "expand start")
+    s = sub(s, "#undef WINO_LOADID\n#undef WINO_EXPAND\n", "#undef WINO_LOADID\n#undef WINO_EXPAND\n    " + st % 7 + "\n", "expand end")
     return s, "conv_wino.hip"
 
 
