@@ -111,7 +111,8 @@ constexpr int ZROUND_FLOATS = 4 * 32 * 32;                      // epilogue exch
 // One workgroup: 32 tiles (128 output pixels) x `nbw` blocks of 32 output channels, one after the other on the same
 // patch (the tile setup and the first fill's latency are paid once; the stages of consecutive channel blocks form one
 // software pipeline).
-template <int D, bool LINEAR, int XCM = 0>      // XCM > 0: + the bottleneck's 1x1 expand convolution over XCM = Cout channels
+template <int D, bool LINEAR, int XCM = 0, int VSH = 0>   // XCM > 0: + the bottleneck's 1x1 expand convolution over XCM = Cout
+                                                        // channels; VSH: a tile row is 1 << VSH "virtual rows" of D tiles (linear)
 __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs a) {
   using G = WinoGeom<D, LINEAR>;
   // (at least 41 KB: 3 workgroups per CU is what the ~150 registers allow anyway, and hipcc then schedules for that)
@@ -133,6 +134,11 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
   const int pass = fastdiv(tq, a.nbm_mul, a.nbm_sh), mb = tq - pass * a.nblk_m;
   const int nb0 = (pass * a.sgs + gi) * a.nbw;
 
+  // R0: first (virtual) tile row of the block.  Linear blocks of maps 2^VSH * D tiles wide (the 14-tile rows of layer2 as
+  // two half rows of 7) count in virtual rows V = R * 2^VSH + part: 32 consecutive tiles of the row-major order either way,
+  // each virtual row with its own patch rows (columns 2 * D * part - 1 ...), so no lane idles on a 14-wide map either
+  static_assert(VSH == 0 || LINEAR, "virtual rows exist in the linear block order only");
+  constexpr int VM = (1 << VSH) - 1;
   int R0, s0, tx0;                                              // (all 32-bit: B * nh * nw < 2^31 is checked by the host)
   if constexpr (LINEAR) {
     const int t0 = mb * 32;
@@ -141,8 +147,9 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
     const int rb = fastdiv(mb, a.nseg_mul, a.nseg_sh), seg = mb - rb * a.nseg;
     R0 = rb * G::NR; s0 = 0; tx0 = seg * D;
   }
-  const int b_first = fastdiv(R0, a.nh_mul, a.nh_sh);           // first image this block touches (wave-uniform)
-  const int ty_first = R0 - b_first * a.nh;
+  const int R0r = R0 >> VSH;                                    // real tile row
+  const int b_first = fastdiv(R0r, a.nh_mul, a.nh_sh);          // first image this block touches (wave-uniform)
+  const int ty_first = R0r - b_first * a.nh;
 
   // ---- weights: MFMA-A fragments straight from L2, one 16-byte load per lane, frequency and 8-channel step; the steps of
   //      consecutive channel blocks are contiguous, so one running scalar offset walks all of this workgroup's stages ----
@@ -166,20 +173,28 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
   const int piece = (G::NP == 1) ? 0 : (xi % G::NP);            // (4 % NP == 0: a wave always gets the same piece of a row)
   static_assert(4 % G::NP == 0, "pieces per row must divide the wave count");
   const int fx = piece * 16 + (lane >> 2);                      // patch pixel of this lane
-  const int fwx = 2 * tx0 - 1 + fx;
   const bool f_lane = fx < G::PWP;                              // lanes past the row's end write nothing (exec mask)
-  const int f_col = ((unsigned)fwx < (unsigned)a.W) ? (fwx * a.in_ps + (((lane & 3) ^ ((fx >> 1) & 3)) * 4)) * 4 : (int)0x80000000u;
+  int f_colv[VM + 1];                                           // lane part of the source offset, per part of a tile row
+#pragma unroll
+  for (int pv = 0; pv <= VM; ++pv) {
+    const int fwx = 2 * (tx0 + pv * D) - 1 + fx;
+    f_colv[pv] = ((unsigned)fwx < (unsigned)a.W) ? (fwx * a.in_ps + (((lane & 3) ^ ((fx >> 1) & 3)) * 4)) * 4 : (int)0x80000000u;
+  }
   int f_off[G::NJ];
   int f_dst[G::NJ];                                             // wave-uniform LDS float offset of the piece (-1: none)
 #pragma unroll
   for (int j = 0; j < G::NJ; ++j) {
     const int i = j * 4 + xi;
     const int r = i / G::NP, fRl = r >> 2, ar = r & 3;
-    const int t = ty_first + fRl;
+    const int Rr = (R0 + fRl) >> VSH, pv = (R0 + fRl) & VM;                  // real tile row and part of it
+    const int t = ty_first + (Rr - R0r);
     const int db = fastdiv(t, a.nh_mul, a.nh_sh), ty = t - db * a.nh;        // image b_first + db
     const int hy = 2 * ty - 1 + ar;
-    const bool rowok = R0 + fRl < a.rows && (unsigned)hy < (unsigned)a.H;
+    const bool rowok = Rr < a.rows && (unsigned)hy < (unsigned)a.H;
     const int rowoff = (db * a.H + hy) * a.W * a.in_ps * 4;
+    int f_col = f_colv[0];
+#pragma unroll
+    for (int k = 1; k <= VM; ++k) f_col = pv == k ? f_colv[k] : f_col;
     f_off[j] = (rowok && f_col >= 0) ? rowoff + f_col : (int)0x80000000u;
     f_dst[j] = i < G::NPIECE ? (fRl * G::RP + ar * G::PWP + piece * 16) * 16 : -1;
   }
@@ -217,7 +232,7 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
   const int tl = tid >> 3, cq = tid & 7;
   const int q2 = s0 + tl;
   const int Rl2 = q2 / D, col2 = q2 - Rl2 * D;
-  const int oR = R0 + Rl2, otx = tx0 + col2;
+  const int oR = (R0 + Rl2) >> VSH, otx = tx0 + ((R0 + Rl2) & VM) * D + col2;
   const int ob = fastdiv(oR, a.nh_mul, a.nh_sh), oty = oR - ob * a.nh;
   const bool o_ok = oR < a.rows && otx < a.nw;
   const bool o_row1 = 2 * oty + 1 < a.H, o_col1 = 2 * otx + 1 < a.W;
@@ -340,10 +355,11 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
     auto pix_off = [&](int tl_, int i_, int j_, int ps) -> int {   // float offset from the block's first image, -1: no such pixel
       const int q = s0 + tl_;
       const int Rq = q / D, cq_ = q - Rq * D;
-      const int t = ty_first + Rq;
+      const int Rr = (R0 + Rq) >> VSH, tx = tx0 + ((R0 + Rq) & VM) * D + cq_;
+      const int t = ty_first + (Rr - R0r);
       const int db = fastdiv(t, a.nh_mul, a.nh_sh), ty = t - db * a.nh;
-      const int oy = 2 * ty + i_, ox = 2 * (tx0 + cq_) + j_;
-      const bool ok = R0 + Rq < a.rows && tx0 + cq_ < a.nw && oy < a.H && ox < a.W;
+      const int oy = 2 * ty + i_, ox = 2 * tx + j_;
+      const bool ok = Rr < a.rows && tx < a.nw && oy < a.H && ox < a.W;
       return ok ? ((db * a.H + oy) * a.W + ox) * ps : -1;
     };
     const size_t img0 = (size_t)b_first * a.H * a.W;
@@ -434,14 +450,14 @@ static void wino_magic(int d, uint32_t& mul, uint32_t& sh) {
   sh = (uint32_t)(l - 1);                                       // (x * mul) >> (31 + l) = umulhi(x, mul) >> (l - 1)
 }
 
-template <int D, bool LINEAR, int XCM = 0>
+template <int D, bool LINEAR, int XCM = 0, int VSH = 0>
 static int wino_launch(WinoArgs& a, hipStream_t stream) {
   using G = WinoGeom<D, LINEAR>;
   const long long rows = a.rows;
   if (rows * a.nw >= 0x7fffff00LL) return HANDS_EINVAL;
   long long nblk_m;
   if (LINEAR) {
-    nblk_m = (rows * D + 31) / 32;
+    nblk_m = (rows * (D << VSH) + 31) / 32;
     a.nseg = 1;
   } else {
     a.nseg = (a.nw + D - 1) / D;
@@ -488,7 +504,7 @@ static int wino_launch(WinoArgs& a, hipStream_t stream) {
   if (XCM > 0 && imgs * a.H * a.W * (long long)(a.out_ps > a.id_ps ? (a.out_ps > a.out3_ps ? a.out_ps : a.out3_ps)
                                                                      : (a.id_ps > a.out3_ps ? a.id_ps : a.out3_ps)) * 4 >= 0x7fffffffLL)
     return HANDS_EINVAL;
-  hipLaunchKernelGGL((conv_wino_f32_kernel<D, LINEAR, XCM>), dim3((unsigned)nwg), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((conv_wino_f32_kernel<D, LINEAR, XCM, VSH>), dim3((unsigned)nwg), dim3(256), 0, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -508,7 +524,7 @@ extern "C" long long hands_conv3x3_winograd_executed_macs(const hands_conv_desc*
   if (!d || !wino_ok(d)) return 0;
   const long long nh = (d->H + 1) / 2, nw = (d->W + 1) / 2, rows = (long long)d->B * nh;
   long long nblk_m;
-  if (nw == 7) nblk_m = (rows * 7 + 31) / 32;
+  if (nw == 7 || nw == 14) nblk_m = (rows * nw + 31) / 32;
   else if (nw % 4 == 0 || nw < 8) nblk_m = (rows + 7) / 8 * ((nw + 3) / 4);
   else nblk_m = (rows + 3) / 4 * ((nw + 7) / 8);
   return 16LL * nblk_m * 32 * d->Cin * d->Cout;
@@ -528,6 +544,7 @@ extern "C" int hands_conv3x3_winograd_f32(const hands_conv_desc* d, const float*
   a.w3 = a.bias3 = a.ident = nullptr; a.out3 = nullptr; a.Cout3 = a.id_ps = a.out3_ps = 0;
   hipStream_t s = (hipStream_t)stream;
   if (a.nw == 7) return wino_launch<7, true>(a, s);
+  if (a.nw == 14) return wino_launch<7, true, 0, 1>(a, s);
   if (a.nw % 4 == 0 || a.nw < 8) return wino_launch<4, false>(a, s);
   return wino_launch<8, false>(a, s);
 }
@@ -560,6 +577,7 @@ extern "C" int hands_bottleneck_wino_expand_f32(const hands_conv_desc* d, const 
   a.w3 = w3_operand; a.bias3 = bias3; a.ident = identity; a.out3 = out; a.Cout3 = Cout3; a.id_ps = id_pix_stride; a.out3_ps = out_pix_stride;
   hipStream_t s = (hipStream_t)stream;
   if (a.nw == 7) return wino_launch<7, true, 64>(a, s);
+  if (a.nw == 14) return wino_launch<7, true, 64, 1>(a, s);
   if (a.nw % 4 == 0 || a.nw < 8) return wino_launch<4, false, 64>(a, s);
   return wino_launch<8, false, 64>(a, s);
 }
