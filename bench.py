@@ -302,6 +302,8 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         model.engine.fuse_expand = os.environ["HANDS_FUSE_EXPAND"] == "1"
     if os.environ.get("HANDS_FUSE_LINK"):          # developer A/B switch
         model.engine.fuse_link = os.environ["HANDS_FUSE_LINK"] == "1"
+    if os.environ.get("HANDS_PIPE_DEPTH") and hasattr(model, "pipeline_depth"):        # developer A/B switch
+        model.pipeline_depth = int(os.environ["HANDS_PIPE_DEPTH"])
     if os.environ.get("HANDS_ASYNC_FORWARD") and hasattr(model, "async_forward"):      # developer A/B switch
         model.async_forward = os.environ["HANDS_ASYNC_FORWARD"] == "1"
     model.overlap_trunks = not serial_headline

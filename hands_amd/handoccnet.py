@@ -97,6 +97,7 @@ class HandOccNet(EngineSwitches, nn.Module):
         self.async_forward = True   # two forwards in flight: call i runs on pipeline stream i & 1 and is joined at the first
                                     # use of its result (stream_xdict), so the launches of consecutive calls fill each other's
                                     # tails -- at 32 samples per GPU a launch is 1-4 tiles per CU, all in phase when alone
+        self.pipeline_depth = 2     # forwards in flight in the pipelined mode (3 and 4 measured: see profiles/README.md)
         self._calls = 0
         self._pipe_done = {}
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_packed())
@@ -251,7 +252,7 @@ class HandOccNet(EngineSwitches, nn.Module):
         pipelined = bool(self.async_forward and self.engine.overlap and dbg is None and self.engine.hook is None
                          and not self.engine._capturing(L, main.cuda_stream))
         if pipelined:
-            par = self._calls & 1
+            par = self._calls % max(1, int(self.pipeline_depth))
             self._calls += 1
             st = self._side_stream(dev, f"pipe{par}")
             K = K.clone()
