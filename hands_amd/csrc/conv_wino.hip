@@ -533,6 +533,7 @@ extern "C" long long hands_conv3x3_winograd_executed_macs(const hands_conv_desc*
 extern "C" int hands_conv3x3_winograd_f32(const hands_conv_desc* d, const float* in, const float* u_packed, const float* bias,
                                           float* out, hands_stream_t stream) {
   if (!d || !in || !u_packed || !bias || !out || !wino_ok(d)) return HANDS_EINVAL;
+  if ((((uintptr_t)in) | ((uintptr_t)u_packed) | ((uintptr_t)bias) | ((uintptr_t)out)) & 15) return HANDS_EINVAL;   // 16-byte accesses
   WinoArgs a;
   a.in = in; a.u = u_packed; a.bias = bias; a.out = out;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
@@ -565,6 +566,9 @@ extern "C" int hands_bottleneck_wino_expand_f32(const hands_conv_desc* d, const 
   if (!d || !in || !u_packed || !bias2 || !t2 || !w3_operand || !bias3 || !identity || !out ||
       !hands_bottleneck_wino_expand_supported(d, Cout3) || id_pix_stride < Cout3 || out_pix_stride < Cout3 ||
       id_pix_stride % 4 || out_pix_stride % 4)
+    return HANDS_EINVAL;
+  if ((((uintptr_t)in) | ((uintptr_t)u_packed) | ((uintptr_t)bias2) | ((uintptr_t)t2) | ((uintptr_t)w3_operand) | ((uintptr_t)bias3) |
+       ((uintptr_t)identity) | ((uintptr_t)out)) & 15)
     return HANDS_EINVAL;
   WinoArgs a;
   a.in = in; a.u = u_packed; a.bias = bias2; a.out = t2;

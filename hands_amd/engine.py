@@ -144,6 +144,7 @@ class ConvEngine:
             S = max(S, min(256 // tiles, pc.Kpad // 128, 32)) if tiles <= 128 else S
         rp = ptr(res, res_off) if res is not None else None
         if (self.winograd and pc.wino is not None and res is None and pre is None and S <= 1 and self.math == "fp32"
+                and (ptr(x, x_off) | ptr(out, out_off)) % 16 == 0        # its accesses are 16 bytes wide
                 and L.hands_conv3x3_winograd_supported(C.byref(d))):
             if hook is not None:
                 self.last_wino_macs = L.hands_conv3x3_winograd_executed_macs(C.byref(d))   # what the matrix cores execute

@@ -134,6 +134,27 @@ def test_winograd_many_tiles_every_output():
     assert err <= 3e-5 * ref.abs().max().item(), err
 
 
+def test_winograd_misaligned_pointers_fall_back_to_the_direct_kernel():
+    """16-byte accesses: the C entry refuses a pointer that is not 16-byte aligned, and the engine routes such a call
+    (a view at an odd float offset) to the direct kernel instead."""
+    L = _lib.lib()
+    x, w, bias = _case(2, 32, 6, 6, 32, 5)
+    pc = pack_conv(w, bias, 1, 1, DEV)
+    flat = torch.zeros(2 * 6 * 6 * 32 + 8, device=DEV)
+    flat[1:1 + x.numel()] = x.reshape(-1).to(DEV)
+    out = torch.empty(2, 6, 6, 32, device=DEV)
+    d = ConvDesc(2, 6, 6, 32, 6, 6, 32, 3, 3, 1, 1, 32, 32, 0, pc.Kpad, 1)
+    assert L.hands_conv3x3_winograd_f32(C.byref(d), ptr(flat, 1), ptr(pc.wino), ptr(pc.bias), ptr(out), _stream()) == 10001
+    seen = []
+    eng = ConvEngine()
+    eng.hook = lambda phase, pc_, npix, st, has_res, kernel: seen.append(kernel)
+    eng.conv(L, pc, flat, 2, 6, 6, out, True, _stream(), x_off=1)
+    torch.cuda.synchronize()
+    assert seen == ["conv_igemm_f32_kernel"] * 2
+    ref = _ref(x, w, bias, 1)
+    assert (out.cpu().double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+
+
 def test_winograd_rejects_what_it_cannot_run():
     L = _lib.lib()
     ok = ConvDesc(2, 14, 14, 64, 14, 14, 64, 3, 3, 1, 1, 64, 64, 0, 576, 1)
