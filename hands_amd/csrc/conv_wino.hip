@@ -15,9 +15,12 @@
 //     (xi: rows (0,-2) (1,+2) (2,-1) (1,-3)), then the four column combinations nu -- 2 LDS reads + 2 adds per V value;
 //   * wave xi accumulates its four nu in 4 x 16 accumulator registers (32 tiles x 32 output channels each), applies
 //     the nu half of A^T . A in registers, and the xi half goes through LDS (32 KB) once per workgroup.
-// Workgroup = 4 waves = 32 tiles (128 output pixels) x 32 output channels, 16 MFMAs (v_mfma_f32_32x32x2_f32) per
-// wave and 8-channel step.  Tiles: flattened tile rows R = b * nh + ty; a block is NR rows x D columns (D = 4 or 8,
-// "rect") or 32 consecutive tiles of the row-major order (D = nw = 7, "linear": 14x14 maps, no idle lanes).
+// Workgroup = 4 waves = 32 tiles (128 output pixels) x 32 output channels (x several channel blocks, one after the other
+// on the same patch), 16 MFMAs (v_mfma_f32_32x32x2_f32) per wave and 8-channel step.  Tiles: flattened tile rows
+// R = b * nh + ty; a block is NR rows x D columns (D = 4 or 8, "rect") or 32 consecutive tiles of the row-major order
+// (D = 7, "linear": 7-tile-wide maps, and 14-tile-wide ones as two virtual half rows per tile row: no idle lanes).
+// Optional expand phase (hands_bottleneck_wino_expand_f32): the bottleneck's 1x1 conv3 + identity + ReLU on the 128 pixels
+// the workgroup has just produced.
 //
 // Numerics: every product and sum is fp32, in a fixed order that depends on the layer only (batch-size invariant,
 // run-to-run deterministic).  Winograd re-associates the 3x3 sum, so results differ from the direct kernel by fp32
