@@ -201,6 +201,11 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
     f_off[j] = (rowok && f_col >= 0) ? rowoff + f_col : (int)0x80000000u;
     f_dst[j] = i < G::NPIECE ? (fRl * G::RP + ar * G::PWP + piece * 16) * 16 : -1;
   }
+#define WINO_FILL1(J, BUF_OFF, CH)                                                                  \
+  do {                                                                                              \
+    if ((J) < G::NJ && f_lane && (((J) + 1) * 4 <= G::NPIECE || f_dst[(J) < G::NJ ? (J) : 0] >= 0))  \
+      wino_dma16(x_rsrc, lds + (BUF_OFF) + f_dst[(J) < G::NJ ? (J) : 0], f_off[(J) < G::NJ ? (J) : 0], (CH) * 64); \
+  } while (0)
 #define WINO_FILL(BUF_OFF, CH)                                                                      \
   do {                                                                                              \
     if (f_lane) {                                                                                   \
@@ -249,7 +254,7 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
 
-#define WINO_STEP(BOFF, S, SET)                                                                     \
+#define WINO_STEP(BOFF, S, SET, DO_FILL, FOFF, CHN)                                                  \
   do {                                                                                              \
     float4 rr[4];                                                                                   \
     _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                 \
@@ -262,6 +267,9 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
     _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                 \
       _Pragma("unroll") for (int nu = 0; nu < 4; ++nu)                                              \
         acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(wr[SET][nu], t), f4e(v[nu], t), acc[nu], 0, 0, 0); \
+      /* the next stage's DMA pieces are issued two at a time behind the four MFMA groups of step 0 (a DMA issue costs  */ \
+      /* the wave ~100 cycles: all of them at the stage's top stalled its own MFMA stream: -1 %) and have step 1 to land */ \
+      if ((S) == 0 && (DO_FILL)) { __builtin_amdgcn_sched_barrier(0); WINO_FILL1(2 * t, FOFF, CHN); WINO_FILL1(2 * t + 1, FOFF, CHN); __builtin_amdgcn_sched_barrier(0); } \
     }                                                                                               \
   } while (0)
 
@@ -275,13 +283,13 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
     const int boff = (s & 1) * (G::BUF_FLOATS * 4);            // bytes (a multiple of 256: the ^ 32 of step 1 is unaffected)
     const int foff = ((s & 1) ^ 1) * G::BUF_FLOATS;
     const int chn = ch + 1 == nch ? 0 : ch + 1;
-    if (s + 1 < nst) WINO_FILL(foff, chn);
+    const bool fillnext = s + 1 < nst;
     WINO_LOADW(1, 2 * s + 1);
     __builtin_amdgcn_sched_barrier(0);                         // (hipcc otherwise sinks the loads to their first use)
-    WINO_STEP(boff, 0, 0);
+    WINO_STEP(boff, 0, 0, fillnext, foff, chn);
     WINO_LOADW(0, s + 1 < nst ? 2 * s + 2 : 2 * s + 1);        // (the last stage re-loads a valid step: no branch)
     __builtin_amdgcn_sched_barrier(0);
-    WINO_STEP(boff, 1, 1);
+    WINO_STEP(boff, 1, 1, fillnext, foff, chn);
     __syncthreads();
     ch = chn;
     if (ch != 0) continue;
