@@ -267,7 +267,7 @@ def workload_text(workload, bz, world):
 # model workloads (hands_light / hamer_light / handoccnet_light)
 # ------------------------------------------------------------------------------------------------------
 def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False, parity_bz=0, layer_report="", math="fp32",
-                  winograd=None):
+                  winograd=None, winograd_scope=None):
     """Returns (result dict, model, cpu state_dict) -- result holds value / ms_per_step / roofline / serial /
     overlapped (+ parity vs the oracle on ``parity_bz`` samples when > 0, rank 0 only)."""
     torch = ctx.torch
@@ -291,8 +291,11 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         model.engine.fuse_pre = os.environ["HANDS_FUSE_PRE"] == "1"
     if os.environ.get("HANDS_FUSE_SPLITK"):        # developer A/B switch
         model.engine.fuse_splitk_reduce = os.environ["HANDS_FUSE_SPLITK"] == "1"
-    if winograd is not None:                       # the model's own default otherwise (HandsLight: on, HandOccNet: off)
+    if winograd is not None:                       # the model's own default otherwise
         model.engine.winograd = bool(winograd)
+    if winograd_scope is not None and hasattr(model, "winograd_scope"):    # HandOccNet: default "backbone"
+        model.winograd_scope = winograd_scope
+        model.invalidate_packed()
     if os.environ.get("HANDS_WINOGRAD"):           # developer A/B switch
         model.engine.winograd = os.environ["HANDS_WINOGRAD"] == "1"
     if os.environ.get("HANDS_WINOGRAD_SCOPE") and hasattr(model, "winograd_scope"):   # developer A/B switch: all | trunk
@@ -686,8 +689,9 @@ def main():
                        "timed_mode": "serial (one HIP stream)" if args.serial else "multi-stream (shipped default)",
                        "latency_mode": bool(args.latency_mode),
                        "conv3x3_stride1": (None if model is None or not hasattr(model, "engine") else
-                                           "winograd_f2x2_3x3 on fp32 MFMA (hands_conv3x3_winograd_f32)" if model.engine.winograd
-                                           else "direct implicit GEMM (hands_conv2d_nhwc_f32)")},
+                                           ("winograd_f2x2_3x3 on fp32 MFMA (hands_conv3x3_winograd_f32)" +
+                                            (f", scope {model.winograd_scope}" if hasattr(model, "winograd_scope") else ""))
+                                           if model.engine.winograd else "direct implicit GEMM (hands_conv2d_nhwc_f32)")},
             "hands_per_sec_per_gpu": res["hands_per_sec_per_gpu"],
             "roofline": res["roofline"], "cpu_baseline": cpu_baseline, "parity": parity,
         }
@@ -703,26 +707,30 @@ def main():
         t_also = time.perf_counter()
         for name, abz, asteps, awarm, pbz in (("hands_light_bf16x3", 256, 10, 3, 8), ("hamer_light", 64, 4, 1, 1),
                                               ("hamer_light_bf16x3", 64, 4, 1, 1), ("handoccnet_light", 32, 10, 3, 2),
-                                              ("handoccnet_light_winograd", 32, 10, 3, 2)):
+                                              ("handoccnet_light_winograd_all", 32, 10, 3, 2)):
             try:
-                math, wino, key = "fp32", None, name
-                if name.endswith("_winograd"):
-                    # opt-in for this model (model.engine.winograd = True): the 3x3 / stride-1 layers as Winograd F(2x2,3x3).
-                    # Same accuracy against fp64 as the direct kernel, but this network amplifies ANY fp32 re-association and one
-                    # golden seed then sits 1.07e-6 m from the reference's own fp32 output (bar 1e-6 m): reported, not the default
-                    name, wino = name[: -len("_winograd")], True
+                math, wino, wscope, key = "fp32", None, None, name
+                if name.endswith("_winograd_all"):
+                    # opt-in for this model (model.winograd_scope = "all"): EVERY 3x3 / stride-1 layer as Winograd F(2x2,3x3), not
+                    # only the backbone's (the default).  Same accuracy against fp64, but this network amplifies ANY fp32
+                    # re-association and one golden seed then sits 1.07e-6 m from the reference's own fp32 output (bar 1e-6 m)
+                    name, wino, wscope = name[: -len("_winograd_all")], True, "all"
                 if name.endswith("_bf16x3"):
                     # separately reported arithmetic mode (HANDS_MATH_BF16X3): three exact bf16 planes per operand,
                     # six bf16 MFMAs per k-16 step, fp32 accumulation.  NEVER the headline `value` above.
                     name, math = name[: -len("_bf16x3")], "bf16x3"
-                r, m, sd = measure_model(ctx, name, abz, asteps, awarm, args, parity_bz=pbz, math=math, winograd=wino)
+                r, m, sd = measure_model(ctx, name, abz, asteps, awarm, args, parity_bz=pbz, math=math, winograd=wino,
+                                         winograd_scope=wscope)
                 if math != "fp32":
                     r["math"] = ("bf16x3: fp32 operands split on the fly into 3 exact bf16 planes, products b_i*b_j with i+j<=2 on "
                                  "v_mfma_f32_32x32x16_bf16, fp32 accumulation; stem, split-K heads, attention and MANO stay fp32 MFMA")
                     r["roofline"]["note"] = ("achieved = ALGORITHMIC fp32 FLOPs / time (fp32-equivalent), priced against THIS mode's own "
                                              "ceiling: the kernel executes 6 bf16 MFMAs per k-16 step, so peak = dense bf16 peak / 6")
                 if wino:
-                    r["conv3x3"] = "opt-in: Winograd F(2x2,3x3) on the fp32 matrix cores (model.engine.winograd = True); default is the direct kernel"
+                    r["conv3x3"] = ("opt-in: Winograd F(2x2,3x3) in EVERY 3x3 / stride-1 layer (model.winograd_scope = 'all'); the "
+                                    "default runs it in the backbone (trunk + FPN smoothing) only")
+                elif name == "handoccnet_light" and math == "fp32":
+                    r["conv3x3"] = "Winograd F(2x2,3x3) in the backbone (trunk + FPN smoothing), direct kernel in the FIT / SET / regressor layers"
                 if math == "fp32" and name != "hands_light" and not args.no_cpu_baseline and not wino:
                     r["cpu_baseline"], r["parity"] = cpu_baseline_small(ctx, name, m, sd, pbz)
                 else:

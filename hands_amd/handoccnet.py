@@ -83,15 +83,16 @@ class HandOccNet(EngineSwitches, nn.Module):
         self._packed = None
         self._packed_dev = None
         self.engine = ConvEngine()
-        # Winograd F(2x2,3x3) for the 3x3 / stride-1 layers is OFF by default here (opt-in: model.engine.winograd = True,
-        # +11 % measured at bz = 256).  Its per-layer error against fp64 is SMALLER than the direct kernel's, but this
-        # network amplifies any fp32 re-association (DESIGN.md "Conditioning note"): with it one of the two golden seeds
-        # lands 1.07e-6 m from the reference's own fp32 output (bar 1e-6 m; direct kernel 5.3e-7 m)
-        self.engine.winograd = False
-        self.winograd_scope = "all"    # which 3x3 / stride-1 layers get Winograd weights at pack time: "all" | "trunk" (the
-                                       # ResNet-50 trunk only: FPN smoothing, FIT convolutions and the regressor's units stay
-                                       # on the direct kernel) -- only read when engine.winograd is on; call invalidate_packed()
-                                       # after changing it
+        # Winograd F(2x2,3x3) (engine.winograd) runs in the BACKBONE only by default (ResNet-50 trunk + FPN smoothing: +8.6 % at 32
+        # samples per GPU); the FIT / SET convolutions and the regressor's units stay on the direct kernel.  Winograd's per-layer
+        # error against fp64 is smaller than the direct kernel's, but this network amplifies ANY fp32 re-association (DESIGN.md
+        # "Conditioning note"): over 16 input seeds the max vertex error against the reference's own fp32 output is 3.7-8.0e-7 m
+        # with the direct kernel everywhere, 4.1-8.5e-7 m with this scope and 3.1-9.0e-7 m with Winograd in every 3x3 / stride-1
+        # layer (tools/hon_parity_sweep.py; the reference itself is 2.0-6.0e-7 m from an fp64 evaluation) -- and with "all" one of
+        # the two golden seeds lands at 1.07e-6 m (bar 1e-6 m; this scope 7.8e-7, direct 6.9e-7).  winograd_scope = "all" is the
+        # opt-in (+14 %), engine.winograd = False the direct kernel everywhere; call invalidate_packed() after changing the scope.
+        self.engine.winograd = True
+        self.winograd_scope = "backbone"   # "all" | "backbone+fit" | "backbone" (trunk + FPN smoothing) | "trunk"
         self.small_map_splitk = True   # call-site constant split-K on maps of <= 8x8 pixels (see _conv_fns)
         self.chunks = 2   # the 2*bz crops run as this many jobs on separate HIP streams (1 = single stream)
         self.async_forward = True   # two forwards in flight: call i runs on pipeline stream i & 1 and is joined at the first
@@ -134,7 +135,9 @@ class HandOccNet(EngineSwitches, nn.Module):
             if bn is not None:
                 s, t = bn_affine(bn)
                 w, b = w * s.view(-1, 1, 1, 1), b * s + t
-            wino = self.winograd_scope == "all" or (self.winograd_scope == "trunk" and p.startswith("backbone.layer"))
+            sc = self.winograd_scope
+            wino = (sc == "all" or (sc == "trunk" and p.startswith("backbone.layer")) or
+                    (sc in ("backbone", "backbone+fit") and p.startswith("backbone.")) or (sc == "backbone+fit" and p.startswith("FIT.")))
             return pack_conv(w, b, stride, pad, dev, cin_pad_to=cin_pad_to, winograd=wino)
 
         def lin(p, **kw):

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); os.environ.setdefault("HANDS_SYNTHETIC_MANO","1")
 import numpy as np, torch, hands_amd
 from hands_amd.weights import synthetic_inputs
 m=hands_amd.apply_recipe(hands_amd.HandOccNet()).eval().to("cuda"); m.async_forward=False
-for scope,w in (("all",False),("all",True),("trunk",True)):
+for scope,w in (("all",False),("all",True),("trunk",True),("backbone",True),("backbone+fit",True)):
     m.engine.winograd=w; m.winograd_scope=scope; m.invalidate_packed()
     for seed in (0,1):
         d=np.load(os.path.join(ROOT, "tests", "golden", f"handoccnet_light_bz2_seed{seed}.npz"))

@@ -31,9 +31,9 @@ for seed in range(n):
     except Exception as e:      # the oracle may not be dtype-generic everywhere
         ref64 = None
     row = []
-    for wino in (False, True, "trunk"):
+    for wino in (False, True, "backbone"):
         model.engine.winograd = bool(wino)
-        scope = "trunk" if wino == "trunk" else "all"
+        scope = "backbone" if wino == "backbone" else "all"
         if model.winograd_scope != scope:
             model.winograd_scope = scope
             model.invalidate_packed()
@@ -42,11 +42,11 @@ for seed in range(n):
         e32 = max((out[f"mano.vertices.{h}"].cpu() - ref32[f"mano.vertices.{h}"]).abs().max().item() for h in "rl")
         e64 = max((out[f"mano.vertices.{h}"].cpu().double() - ref64[f"mano.vertices.{h}"]).abs().max().item() for h in "rl") if ref64 else float("nan")
         row += [e32, e64]
-        nm = {False: "direct", True: "wino", "trunk": "wino-trunk"}[wino]
+        nm = {False: "direct", True: "wino", "backbone": "wino-backbone"}[wino]
         for key, v in ((nm + " vs ref fp32", e32), (nm + " vs fp64", e64)):
             worst[key] = max(worst.get(key, 0.0), v)
     r64 = max((ref32[f"mano.vertices.{h}"].double() - ref64[f"mano.vertices.{h}"]).abs().max().item() for h in "rl") if ref64 else float("nan")
     worst["ref fp32 vs fp64"] = max(worst.get("ref fp32 vs fp64", 0.0), r64)
     print(f"seed {seed}: direct vs ref32 {row[0]:.2e} vs fp64 {row[1]:.2e} | wino vs ref32 {row[2]:.2e} vs fp64 {row[3]:.2e} | "
-          f"wino-trunk vs ref32 {row[4]:.2e} vs fp64 {row[5]:.2e} | ref32 vs fp64 {r64:.2e}")
+          f"wino-backbone vs ref32 {row[4]:.2e} vs fp64 {row[5]:.2e} | ref32 vs fp64 {r64:.2e}")
 print("worst over seeds:", {k: f"{v:.2e}" for k, v in worst.items()})
