@@ -477,10 +477,12 @@ static int wino_launch(WinoArgs& a, hipStream_t stream) {
   a.nblk_n = a.Cout / 32;
   if (nblk_m <= 0 || nblk_m * a.nblk_n > 0x7fffffffLL) return HANDS_EINVAL;
   a.nblk_m = (int)nblk_m;
-  // Channel blocks per workgroup: a workgroup pays ~10 k cycles of tile setup once and ~5 k per channel block (epilogue)
-  // next to ~6.5 k per 16-channel stage (tools/prof_wino.py), so short-K layers want several channel blocks per
-  // workgroup -- but fewer, longer workgroups quantise worse on the chip's 3 x CUs slots.  Cheapest divisor of nblk_n under
-  // that model (a function of the launch geometry only: the arithmetic and its order never depend on it).
+  // Channel blocks per workgroup: a workgroup pays ~4 k cycles of tile setup once and ~4 k per channel block (epilogue)
+  // next to ~6.9 k per 16-channel stage (tools/prof_wino.py), so short-K layers want several channel blocks per
+  // workgroup -- but fewer, longer workgroups quantise worse on the chip's 3 x CUs slots, and a workgroup that walks several
+  // channel blocks re-reads its patch from the Infinity Cache for each (the 128-channel layer: equal time, 2.2x the fabric
+  // reads with 4 blocks per workgroup).  Cheapest divisor of nblk_n under that model, the smaller one on ties (a function of
+  // the launch geometry only: the arithmetic and its order never depend on it).
   const long long slots = 3LL * wino_device_cus();
   const double nch = a.Cin / 16;
   double best = 0.0;
@@ -488,8 +490,8 @@ static int wino_launch(WinoArgs& a, hipStream_t stream) {
   for (int w = 1; w <= a.nblk_n; ++w) {
     if (a.nblk_n % w) continue;
     const long long wgs = nblk_m * (a.nblk_n / w);
-    const double cost = (double)((wgs + slots - 1) / slots) * (10.0 + w * (6.5 * nch + 5.0));
-    if (w == 1 || cost < best) { best = cost; a.nbw = w; }
+    const double cost = (double)((wgs + slots - 1) / slots) * (4.0 + w * (6.9 * nch + 4.0));
+    if (w == 1 || cost < 0.99 * best) { best = cost; a.nbw = w; }
   }
   if (const char* e = getenv("HANDS_WINO_NBW")) {               // developer override (must divide Cout / 32)
     const int w = atoi(e);
