@@ -1,0 +1,131 @@
+"""bench.py's output contract: the headline is the LAST stdout line and stays below 4 KB whatever
+the measurements returned (round 3's single 23 KB line left the driver's record unparsed); every extra measurement is
+its own short line.  Plus the rank-affinity helper (sysfs only).  CPU only: the lines are built from canned results."""
+import importlib.util
+import json
+import os
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def canned():
+    """Round 3's real 23 KB line (committed under profiles/) as the canned measurement."""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_default_full_line.json")))
+    also = full.pop("also")
+    return full, {k: v for k, v in also.items() if isinstance(v, dict)}
+
+
+def test_headline_from_a_real_result_is_short_and_complete(bench, capsys):
+    full, also = canned()
+    assert len(json.dumps(dict(full, also=also))) > 20000                 # the input really is the oversized one
+    for k, v in also.items():
+        print(json.dumps(dict(bench.compact_entry(v), also=k)))
+    print(json.dumps(bench.compact_headline(full, also, "gpurun_out/bench_details.json")))
+    lines = capsys.readouterr().out.splitlines()
+    assert all(len(ln) < 2048 for ln in lines[:-1])
+    assert len(lines[-1]) < bench.HEADLINE_LIMIT == 4096
+    head = json.loads(lines[-1])
+    for k in REQUIRED:
+        assert k in head, k
+    assert head["value"] == full["value"] and head["ms_per_step"] == full["ms_per_step"]
+    assert head["config"]["workload"].startswith("hands_light") and "model" not in head["config"]
+    r = head["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    for k in ("executed_frac", "traffic", "traffic_over_algorithmic", "kernel_ms_per_step", "step_ms_same_mode"):
+        assert k in r, k
+    assert "kernels" not in r and "shapes" not in r and "algorithm_note" not in r
+    c = head["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert set(head["also"]) == set(also) and all(isinstance(v, (int, float)) for v in head["also"].values())
+    # the last 8000 characters of stdout (what the driver keeps) hold the whole headline
+    tail = "\n".join(lines)[-8000:]
+    assert json.loads(tail.splitlines()[-1]) == head
+
+
+def test_headline_survives_pathological_strings_and_errors(bench):
+    full, also = canned()
+    full["config"]["workload"] = "w" * 5000
+    full["cpu_baseline"]["sample"] = "s" * 9000
+    full["roofline"]["kernel"] = "k" * 3000
+    also["boom"] = {"error": "RuntimeError: " + "x" * 10000}
+    line = bench.compact_headline(full, also, "gpurun_out/bench_details.json")
+    s = json.dumps(line)
+    assert len(s) < bench.HEADLINE_LIMIT
+    back = json.loads(s)
+    for k in REQUIRED:
+        assert k in back, k
+    assert back["roofline"]["frac"] == full["roofline"]["frac"] and back["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+    # an errored extra measurement prints a bounded line too (main() truncates the message)
+    assert len(json.dumps(bench.compact_entry({"error": "E" * 300}))) < 512
+
+
+def test_multi_rank_keys_reach_the_headline(bench):
+    full, _ = canned()
+    full.update(n_gpus=8, allgather_us=412.5, host_enqueue_ms_per_step=3.1, per_rank_hands_per_sec={"min": 1.0, "max": 2.0},
+                cpu_baseline=None, parity=None)
+    head = bench.compact_headline(full)
+    assert head["allgather_us"] == 412.5 and head["host_enqueue_ms_per_step"] == 3.1
+    assert head["per_rank_hands_per_sec"] == {"min": 1.0, "max": 2.0} and head["cpu_baseline"] is None
+
+
+# --------------------------------------------------------------------------------------------------------
+def fake_sysfs(tmp_path):
+    """Two sockets: CPU nodes 0/1, GPUs (KFD nodes 2,3) on buses 0x05 (numa 0) and 0x85 (numa 1)."""
+    s = tmp_path / "sys"
+    for idx, (simd, loc) in enumerate([(0, 0), (0, 0), (1024, 0x0500), (1024, 0x8500)]):
+        d = s / "class/kfd/kfd/topology/nodes" / str(idx)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count 64\nsimd_count {simd}\nlocation_id {loc}\ndomain 0\n")
+    for bus, node in (("05", 0), ("85", 1)):
+        d = s / "bus/pci/devices" / f"0000:{bus}:00.0"
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+        (d / "local_cpulist").write_text("0-3\n" if node == 0 else "4-7\n")
+    for node, lst in ((0, "0-3"), (1, "4-7")):
+        d = s / "devices/system/node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(lst + "\n")
+    return str(s)
+
+
+def test_rank_affinity_from_sysfs(tmp_path):
+    from hands_amd import affinity as A
+    assert A.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    sysfs = fake_sysfs(tmp_path)
+    assert A.kfd_gpu_pci_addresses(sysfs) == ["0000:05:00.0", "0000:85:00.0"]
+    assert A.gpu_node_cpus(0, sysfs, env={}) == ({0, 1, 2, 3}, 0, "0000:05:00.0")
+    assert A.gpu_node_cpus(1, sysfs, env={}) == ({4, 5, 6, 7}, 1, "0000:85:00.0")
+    assert A.gpu_node_cpus(0, sysfs, env={"HIP_VISIBLE_DEVICES": "1"})[1] == 1          # cuda:0 is the second GPU
+    assert A.gpu_node_cpus(0, sysfs, env={"ROCR_VISIBLE_DEVICES": "1,0", "HIP_VISIBLE_DEVICES": "1"})[1] == 0
+    assert A.gpu_node_cpus(2, sysfs, env={}) == (None, None, None)
+    assert A.gpu_node_cpus(0, sysfs, env={"HIP_VISIBLE_DEVICES": "GPU-abcdef"}) == (None, None, None)
+
+
+def test_pin_rank_never_widens_or_empties_the_affinity(tmp_path):
+    from hands_amd import affinity as A
+    sysfs = fake_sysfs(tmp_path)
+    have = os.sched_getaffinity(0)
+    try:
+        r = A.pin_rank_to_gpu_node(1, sysfs, env={})
+        want = have & {4, 5, 6, 7}
+        if want:
+            assert r["pinned"] and r["numa_node"] == 1 and os.sched_getaffinity(0) == want
+        else:
+            assert not r["pinned"] and os.sched_getaffinity(0) == have
+        assert A.pin_rank_to_gpu_node(5, sysfs, env={}) == {"pinned": False, "why": "topology not in sysfs"}
+    finally:
+        os.sched_setaffinity(0, have)

@@ -1,0 +1,78 @@
+"""Multi-seed parity of the SHIPPED default routes against the oracle.
+
+Winograd F(2x2,3x3) is the default 3x3 route of hands_light (every stride-1 3x3) and of handoccnet_light's backbone
+(src/models/handoccnet_light/backbone.py:44-65,68-119).  handoccnet_light amplifies any fp32 re-association, so one golden
+seed is not evidence of the margin: here >= 8 input seeds per model run through the HIP default path and must stay within
+the north-star bar -- max vertex error <= 1e-6 m (= 1e-3 mm) and root-aligned MPJPE <= 1e-3 mm -- against the oracle, the
+two golden seeds also against the reference-generated fixtures.  The worst seed is printed and written to
+gpurun_out/parity_sweep_<model>.json (profiles/README.md quotes it)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import hands_amd
+from hands_amd.weights import synthetic_inputs
+from oracle import handoccnet_oracle as HO
+from oracle import hands_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+BAR_M, BAR_MPJPE_MM = 1e-6, 1e-3
+SEEDS = range(10, 20)          # disjoint from the golden seeds (0-2) and the bench sweep (1-8)
+
+
+def _sweep(model, sd, oracle_fwd, name):
+    ar, al = hands_amd.synthetic_mano_asset(True), hands_amd.synthetic_mano_asset(False)
+    rows = []
+    for seed in SEEDS:
+        ci, cm = synthetic_inputs(2, seed)
+        ref = oracle_fwd(sd, ar, al, ci, cm)
+        out = model({k: v.to(DEV) for k, v in ci.items()}, {k: v.to(DEV) for k, v in cm.items()})
+        torch.cuda.synchronize()
+        verr = max((out[f"mano.vertices.{h}"].cpu() - ref[f"mano.vertices.{h}"]).abs().max().item() for h in "rl")
+        mp = max(O.mpjpe_ra_mm(out[f"mano.joints3d.{h}"].cpu(), ref[f"mano.joints3d.{h}"]) for h in "rl")
+        rows.append({"seed": seed, "max_vertex_err_m": verr, "mpjpe_mm": mp})
+    worst = max(rows, key=lambda r: r["max_vertex_err_m"])
+    print(f"{name}: worst of {len(rows)} seeds: seed {worst['seed']} max vertex err {worst['max_vertex_err_m']:.3e} m "
+          f"(bar {BAR_M:.0e}), MPJPE {max(r['mpjpe_mm'] for r in rows):.3e} mm; all: "
+          + " ".join(f"{r['max_vertex_err_m']:.2e}" for r in rows))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump({"model": name, "rows": rows, "worst": worst, "bar_m": BAR_M},
+                  open(os.path.join(ROOT, "gpurun_out", f"parity_sweep_{name}.json"), "w"), indent=1)
+    except OSError:
+        pass
+    return rows, worst
+
+
+def test_hands_light_default_route_multi_seed_parity():
+    model = hands_amd.apply_recipe(hands_amd.HandsLight())
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).eval()
+    assert model.engine.winograd, "the shipped default of HandsLight is the Winograd route"
+    rows, worst = _sweep(model, sd, O.hands_light_forward, "hands_light")
+    assert len(rows) >= 8
+    assert worst["max_vertex_err_m"] <= BAR_M and max(r["mpjpe_mm"] for r in rows) <= BAR_MPJPE_MM, worst
+
+
+def test_handoccnet_default_scope_multi_seed_parity(golden_dir):
+    model = hands_amd.apply_recipe(hands_amd.HandOccNet())
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).eval()
+    assert model.engine.winograd and model.winograd_scope == "backbone", "shipped default: Winograd in the backbone only"
+    rows, worst = _sweep(model, sd, HO.handoccnet_forward, "handoccnet_light")
+    assert len(rows) >= 8
+    assert worst["max_vertex_err_m"] <= BAR_M and max(r["mpjpe_mm"] for r in rows) <= BAR_MPJPE_MM, worst
+    # the two golden seeds against what the REFERENCE ITSELF produced (tests/golden/make_golden_handoccnet.py)
+    for seed in (0, 1):
+        d = np.load(os.path.join(golden_dir, f"handoccnet_light_bz2_seed{seed}.npz"))
+        inputs, meta_info = synthetic_inputs(2, seed, device=DEV)
+        out = model(inputs, meta_info)
+        torch.cuda.synchronize()
+        verr = max(np.abs(out[f"mano.vertices.{h}"].cpu().numpy() - d[f"out/mano.vertices.{h}"]).max() for h in "rl")
+        print(f"handoccnet_light golden seed {seed}: max vertex err vs the reference's own output {verr:.3e} m")
+        assert verr <= BAR_M, (seed, verr)
