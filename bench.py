@@ -376,8 +376,6 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         model.small_map_splitk = os.environ["HANDS_SMALL_MAP_SPLITK"] == "1"
     if os.environ.get("HANDS_FUSE_PRE"):           # developer A/B switch
         model.engine.fuse_pre = os.environ["HANDS_FUSE_PRE"] == "1"
-    if os.environ.get("HANDS_FUSE_SPLITK"):        # developer A/B switch
-        model.engine.fuse_splitk_reduce = os.environ["HANDS_FUSE_SPLITK"] == "1"
     if winograd is not None:                       # the model's own default otherwise
         model.engine.winograd = bool(winograd)
     if winograd_scope is not None and hasattr(model, "winograd_scope"):    # HandOccNet: default "backbone"
@@ -388,10 +386,6 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
     if os.environ.get("HANDS_WINOGRAD_SCOPE") and hasattr(model, "winograd_scope"):   # developer A/B switch: all | trunk
         model.winograd_scope = os.environ["HANDS_WINOGRAD_SCOPE"]
         model.invalidate_packed()
-    if os.environ.get("HANDS_FUSE_EXPAND"):        # developer A/B switch (default: on)
-        model.engine.fuse_expand = os.environ["HANDS_FUSE_EXPAND"] == "1"
-    if os.environ.get("HANDS_FUSE_LINK"):          # developer A/B switch
-        model.engine.fuse_link = os.environ["HANDS_FUSE_LINK"] == "1"
     if os.environ.get("HANDS_PIPE_DEPTH") and hasattr(model, "pipeline_depth"):        # developer A/B switch
         model.pipeline_depth = int(os.environ["HANDS_PIPE_DEPTH"])
     if os.environ.get("HANDS_ASYNC_FORWARD") and hasattr(model, "async_forward"):      # developer A/B switch
@@ -460,9 +454,7 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         if phase == "begin":
             macs = pc.macs_per_pixel * npix
             # algorithmic bytes: input read once + output written once (+ residual read) + weights once
-            if getattr(pc, "alg_bytes_per_pixel", None):     # fused conv3 -> conv1 launch: its own byte count
-                nbytes = pc.alg_bytes_per_pixel * npix + 4.0 * pc.w.numel()
-            elif kernel.startswith("stem_pool"):    # image in (RGB0 NHWC4, or the 3 NCHW planes), pooled 64-channel map out
+            if kernel.startswith("stem_pool"):    # image in (RGB0 NHWC4, or the 3 NCHW planes), pooled 64-channel map out
                 nbytes = 4.0 * (npix * 4 * (3 if "planar" in kernel else 4) + (npix // 4) * 64 + pc.w.numel())
             else:
                 nbytes = 4.0 * (npix * pc.Cout * (2 if has_res else 1) + npix * pc.stride * pc.stride * pc.Cin + pc.w.numel())

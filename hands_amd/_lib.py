@@ -59,9 +59,6 @@ SIGNATURES = {
     "hands_conv2d_nhwc_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P],
     "hands_conv3x3_winograd_supported": [C.POINTER(ConvDesc)],
     "hands_conv3x3_winograd_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
-    "hands_bottleneck_wino_expand_supported": [C.POINTER(ConvDesc), _I],
-    "hands_bottleneck_wino_expand_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P],
-    "hands_bottleneck_link_f32": [_P, _P, _P, _P, _P, _P, _P, _P, C.c_longlong, _I, _P],
     "hands_conv2d_splitk_factor": [C.POINTER(ConvDesc)],
     "hands_conv2d_nhwc_splitk_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_longlong, _P],
     "hands_conv2d_streamk_grid": [C.POINTER(ConvDesc)],
@@ -69,7 +66,6 @@ SIGNATURES = {
     "hands_conv1x1_dual_nhwc_f32": [C.POINTER(ConvDesc), _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "hands_conv2d_nhwc_splitk_n_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P, C.c_longlong, _P],
     "hands_conv2d_nhwc_pre_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _I, _P, C.c_longlong, _P],
-    "hands_conv2d_nhwc_splitk_fused_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P, C.c_longlong, _P, _I, _P],
     "hands_stem_conv_maxpool_nhwc_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hands_stem_conv_maxpool_nchw_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hands_nchw3_to_nhwc4_f32": [_P, _P, _I, _I, _I, _P],
@@ -117,11 +113,11 @@ SIGNATURES = {
     "hands_pack_conv1x1_dual_f64": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
     "hands_pack_mano_f32": [_P] * 10,
     "hands_pack_conv3x3_winograd_f64": [_I, _I, _P, _P],
-    "hands_pack_conv1x1_operand_f32": [_I, _I, _I, _P, _P],
 }
 EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string", "hands_conv2d_workspace_floats", "hands_pack_conv3x3_winograd_floats", "hands_conv3x3_winograd_executed_macs",
                  "hands_conv2d_streamk_workspace_bytes", "hands_stream_is_capturing")
 
+ABI_VERSION = 2      # HANDS_ABI_VERSION of include/hands_hip.h this wrapper was written against
 _lib = None
 
 
@@ -135,6 +131,11 @@ def lib():
             f"hands_amd: {LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C hands_amd/csrc`. There is no CPU fallback.")
     h = C.CDLL(LIB_PATH)
+    h.hands_abi_version.restype = C.c_int
+    if h.hands_abi_version() != ABI_VERSION:
+        # a stale build (e.g. an A/B variant through $HANDS_HIP_LIB) would otherwise fail late with an AttributeError
+        raise RuntimeError(f"hands_amd: {LIB_PATH} has ABI version {h.hands_abi_version()}, this package needs {ABI_VERSION}: "
+                           "rebuild it (`make -C hands_amd/csrc`)")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(h, name)
         fn.argtypes = argtypes

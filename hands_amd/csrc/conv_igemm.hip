@@ -90,12 +90,6 @@ struct ConvArgs {
   int ksplit;         // > 1: deterministic split-K, grid = tiles * ksplit, raw partial sums to `partial`
   float* partial;     // [ksplit][M][part_ps]
   int part_ps;
-  // split-K with the reduction folded into the launch: counters[tile] counts the slices that have stored their partial
-  // tile; the workgroup that arrives LAST adds the slices in ascending order (+ bias, residual, activation: exactly
-  // splitk_reduce_kernel's arithmetic) and resets the counter.  nullptr: two-pass form (splitk_reduce_kernel)
-  int* counters;
-  const float* fin_res;
-  int fin_res_ps, fin_act;
   // PRE instantiations (pointwise layers): the activation operand is leaky_relu(x * pre_scale[k] + pre_shift[k], 0.01) --
   // the eval BatchNorm -> LeakyReLU that PRECEDES the first convolution of a pre-activation residual unit
   // (handoccnet_light/hand_head.py:131-133,170-172), applied on the way into LDS instead of by a launch of its own
@@ -191,7 +185,7 @@ constexpr int SK_SLOT_FLOATS = 4 * 64 * 64;   // one workgroup's accumulators: 4
 // both operands are split on the way into LDS into three bf16 planes whose sum is the fp32 value exactly, and a
 // k-16 step is six v_mfma_f32_32x32x16_bf16 (the products b_i * b_j with i + j <= 2, fp32 accumulation): the
 // dropped terms are <= 2^-24 of a product -- fp32-grade results at 3/8 of the matrix-pipe time.
-template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool FIN = false, bool PRE = false>
+template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool PRE = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int tile, int split, int kt0, int kt1,
                                           const float* acc_in, float* acc_out) {
   constexpr int ROW = PREC ? LDS_ROW_B3 : LDS_ROW;
@@ -582,53 +576,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
       if (m < a.M && n_ok) *reinterpret_cast<float4*>(obase + (size_t)m * ops + n_lane) = v;
     }
   }
-  // FIN: its own instantiation, so that the plain launches' register allocation (128 VGPRs = 4 workgroups per CU) is
-  // not touched by this tail
-  if constexpr (FIN && !STEM) if (part && a.counters != nullptr) {      // (the Cin = 4 stem route keeps the two-pass form)
-    // publish this slice's partial tile (all stores done -> L2 written back at agent scope), count it, and let the last
-    // arrival reduce: the order of the additions is the slice order, never the arrival order -> deterministic
-    int* s_last = reinterpret_cast<int*>(lds);      // the ring / transposition buffers are idle from the barrier on
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      const int old = __hip_atomic_fetch_add(a.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = old == a.ksplit - 1;
-      if (last) {
-        __hip_atomic_store(a.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      *s_last = last;
-    }
-    __syncthreads();
-    if (*s_last != 0) {
-      constexpr int C4 = BN / 4;
-      const size_t slice = (size_t)a.M * a.part_ps;
-      for (int idx = tid; idx < BM * C4; idx += 256) {
-        const int r = idx / C4, c4i = idx - r * C4;
-        const int m = m0 + r, n = n0 + 4 * c4i;
-        if (m >= a.M || n >= a.N) continue;
-        const float* p = a.partial + (size_t)m * a.part_ps + n;
-        float4 v = *reinterpret_cast<const float4*>(p);
-        for (int sl = 1; sl < a.ksplit; ++sl) {
-          const float4 q = *reinterpret_cast<const float4*>(p + sl * slice);
-          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-        }
-        const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-        if (a.fin_res) {
-          const float4 rr = *reinterpret_cast<const float4*>(a.fin_res + (size_t)m * a.fin_res_ps + n);
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-        }
-        *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ps + n) = apply_act(v, a.fin_act);
-      }
-    }
-  }
 #undef LOAD_TILES
 #undef STORE_TILES
 }
 
-template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool FIN = false, bool PRE = false>
+template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool PRE = false>
 __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   constexpr int RING = 2 * (64 * WAVES_M + 64 * WAVES_N) * (PREC ? LDS_ROW_B3 : LDS_ROW);
   __shared__ __attribute__((aligned(16))) float lds[RING > EPI_FLOATS ? RING : EPI_FLOATS];
@@ -639,7 +591,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   const int nk_all = a.Kpad / BK;
   const int kt0 = a.ksplit > 1 ? (int)((long long)split * nk_all / a.ksplit) : 0;
   const int kt1 = a.ksplit > 1 ? (int)((long long)(split + 1) * nk_all / a.ksplit) : nk_all;
-  conv_tile<WAVES_M, WAVES_N, MODE, PREC, FIN, PRE>(a, lds, tile, split, kt0, kt1, nullptr, nullptr);
+  conv_tile<WAVES_M, WAVES_N, MODE, PREC, PRE>(a, lds, tile, split, kt0, kt1, nullptr, nullptr);
 }
 
 // ---- stream-K: persistent workgroups with equal shares of (tile, k-step) units -------------------------------
@@ -724,14 +676,14 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sk_f32_kernel(ConvArgs a, S
   }
 }
 
-template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool FIN = false, bool PRE = false>
+template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool PRE = false>
 int launch(ConvArgs& a, hipStream_t stream) {
   constexpr int BM = 64 * WAVES_M, BN = 64 * WAVES_N;
   a.nblk_m = (a.M + BM - 1) / BM;
   a.nblk_n = (a.N + BN - 1) / BN;
   const long long nwg = (long long)a.nblk_m * a.nblk_n * (a.ksplit > 1 ? a.ksplit : 1);
   if (nwg <= 0 || nwg > 0x7fffffffLL) return HANDS_EINVAL;
-  hipLaunchKernelGGL((conv_igemm_f32_kernel<WAVES_M, WAVES_N, MODE, PREC, FIN, PRE>), dim3((unsigned)nwg), dim3(256), 0,
+  hipLaunchKernelGGL((conv_igemm_f32_kernel<WAVES_M, WAVES_N, MODE, PREC, PRE>), dim3((unsigned)nwg), dim3(256), 0,
                      stream, a);
   return (int)hipGetLastError();
 }
@@ -845,6 +797,7 @@ bool conv_geometry_ok(const hands_conv_desc* d) {
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 ||
       d->pad < 0)
     return false;
+  if ((d->act & HANDS_ACT_MASK) > HANDS_ACT_LEAKY_RELU || (d->act & ~(HANDS_ACT_MASK | HANDS_MATH_BF16X3))) return false;   // unknown code
   if (d->Cin % 4 || d->Cout % 4 || d->Kpad % BK || d->Kpad < d->KH * d->KW * d->Cin) return false;
   if (d->Cin != 4 && d->Cin % 16) return false;
   if (d->in_pix_stride < d->Cin || d->out_pix_stride < d->Cout) return false;
@@ -897,7 +850,7 @@ extern "C" int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, 
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
   a.relu = d->act & HANDS_ACT_MASK;
-  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.counters = nullptr; a.fin_res = nullptr; a.fin_res_ps = 0; a.fin_act = 0; a.pre_scale = nullptr; a.pre_shift = nullptr;
+  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.pre_scale = nullptr; a.pre_shift = nullptr;
   a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
   hipStream_t s = (hipStream_t)stream;
   if (stem) return (d->Cout <= 64) ? launch<4, 1, 1>(a, s) : launch<2, 2, 1>(a, s);
@@ -937,7 +890,7 @@ extern "C" int hands_conv2d_nhwc_streamk_f32(const hands_conv_desc* d, const flo
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
   if (d->act & HANDS_MATH_BF16X3) return hands_conv2d_nhwc_f32(d, in, w_packed, bias, residual, out, stream);
   a.relu = d->act & HANDS_ACT_MASK;
-  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.counters = nullptr; a.fin_res = nullptr; a.fin_res_ps = 0; a.fin_act = 0; a.pre_scale = nullptr; a.pre_shift = nullptr;
+  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.pre_scale = nullptr; a.pre_shift = nullptr;
   a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
   hipStream_t s = (hipStream_t)stream;
   if (pointwise_route_ok(d))
@@ -972,7 +925,7 @@ extern "C" int hands_conv1x1_dual_nhwc_f32(const hands_conv_desc* d, const float
   a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0;
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = 0;
   a.relu = d->act & HANDS_ACT_MASK;
-  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.counters = nullptr; a.fin_res = nullptr; a.fin_res_ps = 0; a.fin_act = 0; a.pre_scale = nullptr; a.pre_shift = nullptr;
+  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.pre_scale = nullptr; a.pre_shift = nullptr;
   a.in2 = in2; a.K0 = d->Cin; a.H2 = H2; a.W2 = W2; a.stride2 = stride2; a.in2_ps = in2_pix_stride;
   hipStream_t s = (hipStream_t)stream;
   if (d->act & HANDS_MATH_BF16X3) return (d->Cout <= 64) ? launch<4, 1, 2, 1>(a, s) : launch<2, 2, 2, 1>(a, s);
@@ -984,7 +937,7 @@ int pre_launch(const hands_conv_desc* d, const float* in, const float* pre_scale
                const float* w_packed, const float* bias, const float* residual, float* out, hands_stream_t stream);
 
 int splitk_launch(const hands_conv_desc* d, const float* in, const float* w_packed, const float* bias, const float* residual,
-                  float* out, int S, float* workspace, long long workspace_floats, int* counters, int n_counters,
+                  float* out, int S, float* workspace, long long workspace_floats,
                   hands_stream_t stream, const float* pre_scale = nullptr, const float* pre_shift = nullptr) {
   if (!d) return HANDS_EINVAL;
   const bool pre = pre_scale != nullptr;
@@ -1007,21 +960,13 @@ int splitk_launch(const hands_conv_desc* d, const float* in, const float* w_pack
   a.relu = HANDS_ACT_NONE;
   a.ksplit = S; a.partial = workspace; a.part_ps = part_ps;
   a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
-  // one launch: the last slice of a tile to arrive reduces it (needs one zeroed, self-resetting counter per tile)
-  const bool narrow = d->Cout <= 64;
-  const long long ntiles = narrow ? ((M + 255) / 256) * ((d->Cout + 63) / 64) : ((M + 127) / 128) * ((d->Cout + 127) / 128);
-  const bool fused = counters != nullptr && ntiles <= n_counters && !stem && !pre;
-  a.counters = fused ? counters : nullptr;
-  a.fin_res = residual; a.fin_res_ps = d->res_pix_stride; a.fin_act = d->act & HANDS_ACT_MASK;
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (pre) rc = (d->Cout <= 64) ? launch<4, 1, 2, 0, false, true>(a, s) : launch<2, 2, 2, 0, false, true>(a, s);
+  if (pre) rc = (d->Cout <= 64) ? launch<4, 1, 2, 0, true>(a, s) : launch<2, 2, 2, 0, true>(a, s);
   else if (stem) rc = (d->Cout <= 64) ? launch<4, 1, 1>(a, s) : launch<2, 2, 1>(a, s);
-  else if (fused && pointwise_route_ok(d)) rc = (d->Cout <= 64) ? launch<4, 1, 2, 0, true>(a, s) : launch<2, 2, 2, 0, true>(a, s);
-  else if (fused) rc = (d->Cout <= 64) ? launch<4, 1, 0, 0, true>(a, s) : launch<2, 2, 0, 0, true>(a, s);
   else if (pointwise_route_ok(d)) rc = (d->Cout <= 64) ? launch<4, 1, 2>(a, s) : launch<2, 2, 2>(a, s);
   else rc = (d->Cout <= 64) ? launch<4, 1, 0>(a, s) : launch<2, 2, 0>(a, s);
-  if (rc || fused) return rc;
+  if (rc) return rc;
   const long long total = M * (d->Cout / 4);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(hands_grid_1d(total, 256)), dim3(256), 0, s, workspace, S, (int)M,
                      d->Cout / 4, part_ps, bias, residual, d->res_pix_stride, out, d->out_pix_stride, d->act & HANDS_ACT_MASK);
@@ -1038,11 +983,11 @@ int pre_launch(const hands_conv_desc* d, const float* in, const float* pre_scale
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
   a.relu = d->act & HANDS_ACT_MASK;
-  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.counters = nullptr; a.fin_res = nullptr; a.fin_res_ps = 0; a.fin_act = 0;
+  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0;
   a.pre_scale = pre_scale; a.pre_shift = pre_shift;
   a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
   hipStream_t s = (hipStream_t)stream;
-  return (d->Cout <= 64) ? launch<4, 1, 2, 0, false, true>(a, s) : launch<2, 2, 2, 0, false, true>(a, s);
+  return (d->Cout <= 64) ? launch<4, 1, 2, 0, true>(a, s) : launch<2, 2, 2, 0, true>(a, s);
 }
 }  // namespace
 
@@ -1050,7 +995,7 @@ extern "C" int hands_conv2d_nhwc_pre_f32(const hands_conv_desc* d, const float* 
                                          const float* pre_shift, const float* w_packed, const float* bias,
                                          const float* residual, float* out, int S, float* workspace,
                                          long long workspace_floats, hands_stream_t stream) {
-  if (S > 1) return splitk_launch(d, in, w_packed, bias, residual, out, S, workspace, workspace_floats, nullptr, 0, stream,
+  if (S > 1) return splitk_launch(d, in, w_packed, bias, residual, out, S, workspace, workspace_floats, stream,
                                   pre_scale, pre_shift);
   return pre_launch(d, in, pre_scale, pre_shift, w_packed, bias, residual, out, stream);
 }
@@ -1058,14 +1003,7 @@ extern "C" int hands_conv2d_nhwc_pre_f32(const hands_conv_desc* d, const float* 
 extern "C" int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
                                               const float* bias, const float* residual, float* out, int S,
                                               float* workspace, long long workspace_floats, hands_stream_t stream) {
-  return splitk_launch(d, in, w_packed, bias, residual, out, S, workspace, workspace_floats, nullptr, 0, stream);
-}
-
-extern "C" int hands_conv2d_nhwc_splitk_fused_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
-                                                  const float* bias, const float* residual, float* out, int S,
-                                                  float* workspace, long long workspace_floats, int* counters,
-                                                  int n_counters, hands_stream_t stream) {
-  return splitk_launch(d, in, w_packed, bias, residual, out, S, workspace, workspace_floats, counters, n_counters, stream);
+  return splitk_launch(d, in, w_packed, bias, residual, out, S, workspace, workspace_floats, stream);
 }
 
 extern "C" int hands_conv2d_nhwc_splitk_f32(const hands_conv_desc* d, const float* in, const float* w_packed,

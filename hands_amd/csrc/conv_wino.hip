@@ -19,8 +19,6 @@
 // on the same patch), 16 MFMAs (v_mfma_f32_32x32x2_f32) per wave and 8-channel step.  Tiles: flattened tile rows
 // R = b * nh + ty; a block is NR rows x D columns (D = 4 or 8, "rect") or 32 consecutive tiles of the row-major order
 // (D = 7, "linear": 7-tile-wide maps, and 14-tile-wide ones as two virtual half rows per tile row: no idle lanes).
-// Optional expand phase (hands_bottleneck_wino_expand_f32): the bottleneck's 1x1 conv3 + identity + ReLU on the 128 pixels
-// the workgroup has just produced.
 //
 // Numerics: every product and sum is fp32, in a fixed order that depends on the layer only (batch-size invariant,
 // run-to-run deterministic).  Winograd re-associates the 3x3 sum, so results differ from the direct kernel by fp32
@@ -28,6 +26,7 @@
 // direct algorithm's).  Replaces F.conv2d(3x3, s1, p1) + eval BatchNorm2d (folded) + ReLU of
 // src/nets/backbone/resnet.py:140-142 (conv2 / bn2 / relu of every stride-1 Bottleneck).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 #include "hands_hip.h"
@@ -49,13 +48,6 @@ struct WinoArgs {
   int nblk_m, nblk_n, nseg;
   int rows;                         // B * nh flattened tile rows
   int nbw, ngrp;                    // channel blocks per workgroup (divides nblk_n), groups = nblk_n / nbw
-  // EXPAND kernels (hands_bottleneck_wino_expand_f32): the block's conv3 (1x1, Cmid -> Cout3) + bn3 + identity + ReLU on the
-  // 128 pixels this workgroup has just produced, while they are still in the XCD's L2
-  const float* __restrict__ w3;     // [Cout3 / 32][Cmid / 8][lane 64][4]  (hands_pack_conv1x1_operand_f32)
-  const float* __restrict__ bias3;
-  const float* ident;               // (B, H, W, Cout3) residual, pixel stride id_ps
-  float* out3;                      // (B, H, W, Cout3), pixel stride out3_ps
-  int Cout3, id_ps, out3_ps;
   int sgs;                          // groups per pass of the tile order (divides ngrp): their weights fit an XCD's L2
   uint32_t nh_mul, nh_sh, sgs_mul, sgs_sh, nbm_mul, nbm_sh, nseg_mul, nseg_sh;   // magic numbers: x / nh, / sgs, / nblk_m, / nseg
 };
@@ -103,6 +95,7 @@ struct WinoGeom {
   static constexpr int NP = (PWP + 15) / 16;                    // pieces per input row
   static constexpr int NPIECE = NR * 4 * NP;
   static constexpr int NJ = (NPIECE + 3) / 4;                   // per wave
+  static_assert(NJ <= 8, "WINO_STEP issues the next stage's DMA pieces as J = 2t, 2t + 1 for t = 0..3: at most 8 per wave");
   static constexpr int BUF_FLOATS = ((NR * RP * 16 + 63) / 64) * 64;
 };
 
@@ -114,8 +107,7 @@ constexpr int ZROUND_FLOATS = 4 * 32 * 32;                      // epilogue exch
 // One workgroup: 32 tiles (128 output pixels) x `nbw` blocks of 32 output channels, one after the other on the same
 // patch (the tile setup and the first fill's latency are paid once; the stages of consecutive channel blocks form one
 // software pipeline).
-template <int D, bool LINEAR, int XCM = 0, int VSH = 0>   // XCM > 0: + the bottleneck's 1x1 expand convolution over XCM = Cout
-                                                        // channels; VSH: a tile row is 1 << VSH "virtual rows" of D tiles (linear)
+template <int D, bool LINEAR, int VSH = 0>   // VSH: a tile row is 1 << VSH "virtual rows" of D tiles (linear)
 __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs a) {
   using G = WinoGeom<D, LINEAR>;
   // (at least 41 KB: 3 workgroups per CU is what the ~150 registers allow anyway, and hipcc then schedules for that)
@@ -350,108 +342,31 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
 #undef WINO_STEP
 #undef WINO_LOADW
 #undef WINO_FILL
-
-  if constexpr (XCM > 0) {
-    // ---- conv3 of the bottleneck on this workgroup's 128 pixels (resnet.py:146-154): out3 = relu(W3 . t2 + b3 + identity).
-    //      t2 = what the stages above have just stored (all XCM channels: nbw = all channel blocks); it is read back from L2
-    //      (sc1 loads: this CU's L1 is bypassed) as the MFMA B operand, W3 arrives in operand order like the Winograd weights,
-    //      and the k order (8 kk + t, 8 kk + 4 + t) and the epilogue ((acc + bias) + identity, max 0) are conv_igemm's: the
-    //      same bits as the separate hands_conv2d_nhwc_f32 launch.  Identity reads and output writes of this phase overlap the
-    //      stages of the CU's other workgroups -- as separate launches they are an HBM-bound kernel of their own (77 TFLOP/s).
-    static_assert(XCM % 8 == 0 && XCM <= 64, "B and A fragments of the expand phase live in registers");
-    constexpr int NKK = XCM / 8;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's t2 stores have reached the L2
-    __syncthreads();
-    // this lane's pixel as MFMA column: tile 8 xi + (l31 >> 2), output pixel (i, j) = ((l31 >> 1) & 1, l31 & 1)
-    auto pix_off = [&](int tl_, int i_, int j_, int ps) -> int {   // float offset from the block's first image, -1: no such pixel
-      const int q = s0 + tl_;
-      const int Rq = q / D, cq_ = q - Rq * D;
-      const int Rr = (R0 + Rq) >> VSH, tx = tx0 + ((R0 + Rq) & VM) * D + cq_;
-      const int t = ty_first + (Rr - R0r);
-      const int db = fastdiv(t, a.nh_mul, a.nh_sh), ty = t - db * a.nh;
-      const int oy = 2 * ty + i_, ox = 2 * tx + j_;
-      const bool ok = Rr < a.rows && tx < a.nw && oy < a.H && ox < a.W;
-      return ok ? ((db * a.H + oy) * a.W + ox) * ps : -1;
-    };
-    const size_t img0 = (size_t)b_first * a.H * a.W;
-    const __amdgpu_buffer_rsrc_t t2_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + img0 * a.out_ps, 0, (int)0x80000000u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w3), 0, (int)0x80000000u, 0x00020000);
-    const int bpo = pix_off(8 * xi + (l31 >> 2), (l31 >> 1) & 1, l31 & 1, a.out_ps);
-    float4 bq[NKK];
-#pragma unroll
-    for (int kk = 0; kk < NKK; ++kk)
-      bq[kk] = f4(__builtin_amdgcn_raw_buffer_load_b128(t2_rsrc, bpo >= 0 ? (bpo + 8 * kk + 4 * half) * 4 : (int)0x80000000u, 0, 17));
-    // epilogue rows: pass p handles pixel 8 p + (lane >> 3) of the wave's 32, 16-byte quad lane & 7 of the 32-channel block
-    int eo_id[4], eo_out[4];
-#pragma unroll
-    for (int p4 = 0; p4 < 4; ++p4) {
-      const int n = 8 * p4 + (lane >> 3);
-      eo_id[p4] = pix_off(8 * xi + (n >> 2), (n >> 1) & 1, n & 1, a.id_ps);
-      eo_out[p4] = pix_off(8 * xi + (n >> 2), (n >> 1) & 1, n & 1, a.out3_ps);
-    }
-    const float* idp = a.ident + img0 * a.id_ps + (lane & 7) * 4;
-    float* outp = a.out3 + img0 * a.out3_ps + (lane & 7) * 4;
-    float* sE = lds + xi * 1024;                               // this wave's 32 x 32 transposition tile (rows of 8 quads, swizzled)
-    const int nb3n = a.Cout3 >> 5;
-    // One weight register set, re-loaded fragment by fragment for the next channel block right after its four MFMAs (a whole
-    // block of cover); the identity rows are requested TWO blocks ahead into a ring of three register sets: an HBM read takes
-    // several microseconds under load, a block's 32 MFMAs take one.
-    float4 aq[NKK], idv[3][4];
-#define WINO_LOADID(SET, NB3)                                                                      \
-    do {                                                                                            \
-      _Pragma("unroll") for (int p4 = 0; p4 < 4; ++p4)                                              \
-        idv[SET][p4] = (eo_id[p4] >= 0 && (NB3) < nb3n) ? *reinterpret_cast<const float4*>(idp + eo_id[p4] + (NB3) * 32) \
-                                                        : make_float4(0.f, 0.f, 0.f, 0.f);          \
-    } while (0)
-#define WINO_EXPAND(SET, NB3)                                                                      \
-    do {                                                                                            \
-      WINO_LOADID((SET + 2) % 3, (NB3) + 2);                                                        \
-      const int nxt = (NB3) + 1 < nb3n ? (NB3) + 1 : (NB3);                                         \
-      f32x16 c3;                                                                                    \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) c3[r] = 0.f;                                   \
-      _Pragma("unroll") for (int kk = 0; kk < NKK; ++kk) {                                          \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                               \
-          c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(aq[kk], t), f4e(bq[kk], t), c3, 0, 0, 0);   \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
-        aq[kk] = f4(__builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, lane * 16 + kk * 1024, nxt * (NKK * 1024), 0)); \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
-      }                                                                                             \
-      const float4 b3 = *reinterpret_cast<const float4*>(a.bias3 + (NB3) * 32 + (lane & 7) * 4);     \
-      _Pragma("unroll") for (int g = 0; g < 4; ++g)      /* channel quad 2 g + half of pixel l31 */  \
-        *reinterpret_cast<float4*>(sE + (l31 * 8 + ((2 * g + half) ^ (l31 & 7))) * 4) =              \
-            make_float4(c3[4 * g + 0], c3[4 * g + 1], c3[4 * g + 2], c3[4 * g + 3]);                \
-      _Pragma("unroll") for (int p4 = 0; p4 < 4; ++p4) {                                            \
-        const int n = 8 * p4 + (lane >> 3);                                                         \
-        const float4 c = *reinterpret_cast<const float4*>(sE + (n * 8 + ((lane & 7) ^ (n & 7))) * 4); \
-        float4 y = add4(add4(c, b3), idv[SET][p4]);                                                 \
-        y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);  \
-        if (eo_out[p4] >= 0) *reinterpret_cast<float4*>(outp + eo_out[p4] + (NB3) * 32) = y;        \
-      }                                                                                             \
-    } while (0)
-#pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) aq[kk] = f4(__builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, lane * 16 + kk * 1024, 0, 0));
-    WINO_LOADID(0, 0);
-    WINO_LOADID(1, 1);
-    for (int nb3 = 0; nb3 < nb3n; nb3 += 3) {
-      WINO_EXPAND(0, nb3);
-      if (nb3 + 1 < nb3n) WINO_EXPAND(1, nb3 + 1);
-      if (nb3 + 2 < nb3n) WINO_EXPAND(2, nb3 + 2);
-    }
-#undef WINO_LOADID
-#undef WINO_EXPAND
-  }
 }
 
 }  // namespace
 
+// CU count of the CURRENT device (a launch goes to the device its stream belongs to = the caller's current device), cached per
+// device ordinal; relaxed atomics: concurrent first calls store the same value.
 static int wino_device_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev].store(n, std::memory_order_relaxed);
   }
-  return cus;
+  return n;
 }
+
+// Developer overrides (tests sweep them): read once per process.
+static int wino_env_int(const char* name) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : 0;
+}
+static int wino_env_nbw() { static const int v = wino_env_int("HANDS_WINO_NBW"); return v; }
+static int wino_env_sgs() { static const int v = wino_env_int("HANDS_WINO_SGS"); return v; }
 
 static void wino_magic(int d, uint32_t& mul, uint32_t& sh) {
   if (d <= 1) { mul = 0; sh = 0; return; }
@@ -461,7 +376,7 @@ static void wino_magic(int d, uint32_t& mul, uint32_t& sh) {
   sh = (uint32_t)(l - 1);                                       // (x * mul) >> (31 + l) = umulhi(x, mul) >> (l - 1)
 }
 
-template <int D, bool LINEAR, int XCM = 0, int VSH = 0>
+template <int D, bool LINEAR, int VSH = 0>
 static int wino_launch(WinoArgs& a, hipStream_t stream) {
   using G = WinoGeom<D, LINEAR>;
   const long long rows = a.rows;
@@ -493,37 +408,39 @@ static int wino_launch(WinoArgs& a, hipStream_t stream) {
     const double cost = (double)((wgs + slots - 1) / slots) * (4.0 + w * (6.9 * nch + 4.0));
     if (w == 1 || cost < 0.99 * best) { best = cost; a.nbw = w; }
   }
-  if (const char* e = getenv("HANDS_WINO_NBW")) {               // developer override (must divide Cout / 32)
-    const int w = atoi(e);
-    if (w >= 1 && a.nblk_n % w == 0) a.nbw = w;
-  }
-  if (XCM > 0) a.nbw = a.nblk_n;                                // the expand phase needs all channels of its 128 pixels
+  if (const int w = wino_env_nbw(); w >= 1 && a.nblk_n % w == 0) a.nbw = w;   // developer override (must divide Cout / 32)
   const int ngrp = a.ngrp = a.nblk_n / a.nbw;
   const long long nwg = nblk_m * ngrp;
   wino_magic(a.nh, a.nh_mul, a.nh_sh);
   a.sgs = 1;
   for (int g = 1; g <= ngrp; ++g)                               // largest divisor of ngrp whose weights are <= 2 MB
     if (ngrp % g == 0 && (long long)g * a.nbw * 2048 * a.Cin <= (2LL << 20)) a.sgs = g;
-  if (const char* e = getenv("HANDS_WINO_SGS")) {               // developer override (must divide the group count)
-    const int g = atoi(e);
-    if (g >= 1 && ngrp % g == 0) a.sgs = g;
-  }
+  if (const int g = wino_env_sgs(); g >= 1 && ngrp % g == 0) a.sgs = g;       // developer override (must divide the group count)
   wino_magic(a.sgs, a.sgs_mul, a.sgs_sh);
   wino_magic(a.nblk_m, a.nbm_mul, a.nbm_sh);
   wino_magic(a.nseg, a.nseg_mul, a.nseg_sh);
   // 32-bit byte offsets from the first image a block touches
   const long long imgs = G::NR / a.nh + 2;
   if (imgs * a.H * a.W * a.in_ps * 4 >= 0x7fffffffLL) return HANDS_EINVAL;
-  if (XCM > 0 && imgs * a.H * a.W * (long long)(a.out_ps > a.id_ps ? (a.out_ps > a.out3_ps ? a.out_ps : a.out3_ps)
-                                                                     : (a.id_ps > a.out3_ps ? a.id_ps : a.out3_ps)) * 4 >= 0x7fffffffLL)
-    return HANDS_EINVAL;
-  hipLaunchKernelGGL((conv_wino_f32_kernel<D, LINEAR, XCM, VSH>), dim3((unsigned)nwg), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((conv_wino_f32_kernel<D, LINEAR, VSH>), dim3((unsigned)nwg), dim3(256), 0, stream, a);
   return (int)hipGetLastError();
+}
+
+// The 32-bit offset / grid limits of wino_launch for ANY of its block geometries (NR <= 8 tile rows per block): a layer
+// that passes here launches; one that does not takes the direct kernel (hands_conv3x3_winograd_supported() == 0).
+static bool wino_sizes_ok(const hands_conv_desc* d) {
+  const long long nh = (d->H + 1) / 2, nw = (d->W + 1) / 2, rows = (long long)d->B * nh;
+  if (rows >= 0x7fffff00LL || rows * nw >= 0x7fffff00LL) return false;
+  const long long nblk_m_max = (rows * 14 + 31) / 32 + rows * ((nw + 3) / 4);      // >= every geometry's block count
+  if (nblk_m_max * (d->Cout / 32) > 0x7fffffffLL) return false;
+  const long long imgs = 8 / nh + 2;
+  const long long ps = d->in_pix_stride > d->out_pix_stride ? d->in_pix_stride : d->out_pix_stride;
+  return imgs * d->H * d->W * ps * 4 < 0x7fffffffLL;
 }
 
 static bool wino_ok(const hands_conv_desc* d) {
   const int act = d->act & HANDS_ACT_MASK;
-  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->H && d->Wo == d->W && d->B > 0 && d->H > 0 &&
+  return wino_sizes_ok(d) && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->H && d->Wo == d->W && d->B > 0 && d->H > 0 &&
          d->W > 0 && d->Cin >= 16 && d->Cin % 16 == 0 && d->Cout >= 32 && d->Cout % 32 == 0 && d->in_pix_stride >= d->Cin &&
          d->out_pix_stride >= d->Cout && d->in_pix_stride % 4 == 0 && d->out_pix_stride % 4 == 0 &&
          (act == HANDS_ACT_NONE || act == HANDS_ACT_RELU || act == HANDS_ACT_LEAKY_RELU) && !(d->act & HANDS_MATH_BF16X3);
@@ -555,46 +472,9 @@ extern "C" int hands_conv3x3_winograd_f32(const hands_conv_desc* d, const float*
   if ((long long)d->B * a.nh >= 0x7fffff00LL) return HANDS_EINVAL;
   a.rows = d->B * a.nh;
   a.nblk_m = a.nblk_n = a.nseg = a.nbw = a.ngrp = a.sgs = 0;
-  a.w3 = a.bias3 = a.ident = nullptr; a.out3 = nullptr; a.Cout3 = a.id_ps = a.out3_ps = 0;
   hipStream_t s = (hipStream_t)stream;
   if (a.nw == 7) return wino_launch<7, true>(a, s);
-  if (a.nw == 14) return wino_launch<7, true, 0, 1>(a, s);
+  if (a.nw == 14) return wino_launch<7, true, 1>(a, s);
   if (a.nw % 4 == 0 || a.nw < 8) return wino_launch<4, false>(a, s);
   return wino_launch<8, false>(a, s);
-}
-
-// conv2 (3x3, Winograd) + bn2 + relu  ->  conv3 (1x1 expand) + bn3 + identity + relu of a stride-1 Bottleneck without a
-// downsample branch (src/nets/backbone/resnet.py:140-154) in ONE launch.  `d` describes conv2 exactly as for
-// hands_conv3x3_winograd_f32 (d->Cout = planes = 64, act = RELU); t2 (B, H, W, planes) is still written (the block's
-// conv2 output, pixel stride d->out_pix_stride) and read back from L2 by the workgroup that produced it.
-// Same bits as hands_conv3x3_winograd_f32 followed by hands_conv2d_nhwc_f32(conv3, residual = identity, RELU).
-extern "C" int hands_bottleneck_wino_expand_supported(const hands_conv_desc* d, int Cout3) {
-  return d && wino_ok(d) && d->Cout == 64 && (d->act & HANDS_ACT_MASK) == HANDS_ACT_RELU && Cout3 >= 32 && Cout3 % 32 == 0 ? 1 : 0;
-}
-
-extern "C" int hands_bottleneck_wino_expand_f32(const hands_conv_desc* d, const float* in, const float* u_packed, const float* bias2,
-                                                float* t2, const float* w3_operand, const float* bias3, int Cout3,
-                                                const float* identity, int id_pix_stride, float* out, int out_pix_stride,
-                                                hands_stream_t stream) {
-  if (!d || !in || !u_packed || !bias2 || !t2 || !w3_operand || !bias3 || !identity || !out ||
-      !hands_bottleneck_wino_expand_supported(d, Cout3) || id_pix_stride < Cout3 || out_pix_stride < Cout3 ||
-      id_pix_stride % 4 || out_pix_stride % 4)
-    return HANDS_EINVAL;
-  if ((((uintptr_t)in) | ((uintptr_t)u_packed) | ((uintptr_t)bias2) | ((uintptr_t)t2) | ((uintptr_t)w3_operand) | ((uintptr_t)bias3) |
-       ((uintptr_t)identity) | ((uintptr_t)out)) & 15)
-    return HANDS_EINVAL;
-  WinoArgs a;
-  a.in = in; a.u = u_packed; a.bias = bias2; a.out = t2;
-  a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
-  a.nh = (d->H + 1) / 2; a.nw = (d->W + 1) / 2;
-  a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.act = HANDS_ACT_RELU;
-  if ((long long)d->B * a.nh >= 0x7fffff00LL) return HANDS_EINVAL;
-  a.rows = d->B * a.nh;
-  a.nblk_m = a.nblk_n = a.nseg = a.nbw = a.ngrp = a.sgs = 0;
-  a.w3 = w3_operand; a.bias3 = bias3; a.ident = identity; a.out3 = out; a.Cout3 = Cout3; a.id_ps = id_pix_stride; a.out3_ps = out_pix_stride;
-  hipStream_t s = (hipStream_t)stream;
-  if (a.nw == 7) return wino_launch<7, true, 64>(a, s);
-  if (a.nw == 14) return wino_launch<7, true, 64, 1>(a, s);
-  if (a.nw % 4 == 0 || a.nw < 8) return wino_launch<4, false, 64>(a, s);
-  return wino_launch<8, false, 64>(a, s);
 }

@@ -177,18 +177,4 @@ int hands_pack_conv3x3_winograd_f64(int Cout, int Cin, const double* w_oihw, flo
   return 0;
 }
 
-// 1x1 weights in MFMA-A operand order for the expand phase of hands_bottleneck_wino_expand_f32:
-// [Cout / 32][Cin / 8][lane 64][4], lane l holds output channel 32 nb + (l & 31), input channels 8 kk + 4 (l >> 5) + 0..3.
-// `w_packed` is the [Cout_pad][Kpad] form hands_pack_conv_f64 produced for the same layer (a pure permutation: same bits).
-int hands_pack_conv1x1_operand_f32(int Cout, int Cin, int Kpad, const float* w_packed, float* w_operand) {
-  if (!w_packed || !w_operand || Cout <= 0 || Cin <= 0 || Cout % 32 || Cin % 8 || Kpad < Cin) return HANDS_EINVAL;
-  const int nkk = Cin / 8;
-  for (int o = 0; o < Cout; ++o)
-    for (int c = 0; c < Cin; ++c) {
-      const int nb = o / 32, kk = c / 8, h = (c % 8) / 4, e = c % 4;
-      w_operand[((((long long)nb * nkk + kk) * 64) + h * 32 + (o % 32)) * 4 + e] = w_packed[(long long)o * Kpad + c];
-    }
-  return 0;
-}
-
 }  // extern "C"

@@ -113,9 +113,11 @@ def gather_predictions(out: dict, group=None, global_bz: int | None = None) -> x
             # a backend / version without the single-buffer form (older gloo: "no support for _allgather_base");
             # every rank takes this branch together (same backend), the choice is cached per backend and device type.
             # Anything else (a real collective failure) is re-raised.
+            # Only the backend's own "this collective does not exist" messages count -- a real failure on ONE rank that
+            # happened to say "not supported" must not make that rank issue a different collective than its peers (hang).
             msg = str(e).lower()
             if not isinstance(e, NotImplementedError) and not any(
-                    t in msg for t in ("allgather_base", "all_gather_into_tensor", "not support", "not implemented")):
+                    t in msg for t in ("allgather_base", "all_gather_into_tensor", "allgather_into_tensor")):
                 raise
             _single_buffer_gather[(dist.get_backend(group), flat.device.type)] = False
     if not _single_buffer_gather.get((dist.get_backend(group), flat.device.type), True):

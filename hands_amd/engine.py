@@ -38,23 +38,9 @@ class ConvEngine:
         self.winograd = True          # 3x3 / stride 1 / pad 1 layers as Winograd F(2x2,3x3) on the fp32 matrix cores
                                       # (hands_conv3x3_winograd_f32: 2.25x fewer multiplications; fp32 throughout, results
                                       # differ from the direct kernel by fp32 rounding).  False = the direct implicit GEMM
-        self.fuse_expand = False      # stride-1 bottlenecks with 64 planes and no downsample branch (layer1): conv2 (Winograd) and
-                                      # conv3 + identity + ReLU as ONE launch (hands_bottleneck_wino_expand_f32): the workgroup that
-                                      # produced 128 pixels of t2 runs conv3 on them (t2 read back from L2, identity rows requested
-                                      # two channel blocks ahead).  Bit-identical to the two launches; measured NEUTRAL (round 3:
-                                      # 1.30-1.39 ms against 1.27-1.30 ms per 512-image bottleneck half, forward 11.40 k hands/s
-                                      # either way): the expand phase is HBM-bound at its share of the bus (60 k of a workgroup's
-                                      # 156 k cycles) and slows the Winograd stages of its neighbours (9.4 k instead of 6.8 k
-                                      # cycles per stage) by what it saves.  Opt-in, kept as the tested reference of the fusion.
         self.fuse_mano = True         # MANOHead.forward of both hands as one launch (hands_mano_heads_f32)
         self.fuse_pre = True          # handoccnet_light's pre-activation units: BatchNorm -> LeakyReLU folded into the operand
                                       # staging of the unit's first (pointwise) convolution (hands_conv2d_nhwc_pre_f32)
-        self.fuse_link = False        # layer1: conv3 + identity + ReLU of block i and conv1 + ReLU of block i + 1 as one
-                                      # launch (hands_bottleneck_link_f32): `out` is not re-read from HBM; bit-identical.
-                                      # Built and measured (profiles/README.md, round 3): its 64-pixel x 256-channel LDS tile
-                                      # and ~230 VGPRs allow 2 waves per SIMD, and the memory phase of a tile does not overlap
-                                      # its two MFMA phases: 4.8 ms per forward against 4.0 ms for the separate launches
-                                      # (4 waves per SIMD).  Kept as an opt-in and as the tested reference of the seam.
         self.hook = None              # callable(phase, pc, npix, stream_handle, has_res, kernel): bench.py brackets
                                       # every MFMA launch (conv_igemm and the fused stem) with events; `kernel` is the
                                       # kernel the launch really runs (conv_igemm_f32_kernel / conv_igemm_sk_f32_kernel =
@@ -63,16 +49,10 @@ class ConvEngine:
         self._splitk_ws = {}          # (device, stream handle) -> workspace tensor
         self._sk_ws = {}              # (device, stream handle) -> [zeroed stream-K workspace, epoch counter]
         self._capture_ws = {}         # split-K workspaces of launches recorded into a hipGraph (graph memory pool)
-        self.fuse_splitk_reduce = False  # split-K as ONE launch: the last slice of a tile to arrive reduces it (per-tile
-                                         # arrival counters; fixed slice order -> same bits as the two-pass form).  Built,
-                                         # tested bit-identical, measured SLOWER (round 3: handoccnet_light at 32/GPU -3.5 %,
-                                         # hands_light serial +0.7 ms): every workgroup pays an agent-scope release (L2
-                                         # write-back) that the kernel boundary of the two-pass form gives for free.  Opt-in.
-        self._splitk_counters = {}    # (device, stream handle[, "capture"]) -> zeroed int32 counters, self-resetting
 
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
-        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "winograd", "fuse_expand", "fuse_mano", "fuse_pre", "fuse_link", "fuse_splitk_reduce", "stream_k", "math"):
+        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "winograd", "fuse_mano", "fuse_pre", "stream_k", "math"):
             setattr(e, k, getattr(self, k))
         return e
 
@@ -81,7 +61,7 @@ class ConvEngine:
         stream handle the launch went to: a model calls this when it drops its side streams (``invalidate_packed``,
         ``.to()``), so a later stream that happens to get a recycled handle starts from a fresh, zero-filled
         workspace and no destroyed stream keeps 64 MB pinned."""
-        for table in (self._splitk_ws, self._sk_ws, self._capture_ws, self._splitk_counters):
+        for table in (self._splitk_ws, self._sk_ws, self._capture_ws):
             for key in [k for k in table if dev is None or k[0] == dev]:
                 del table[key]
 
@@ -109,16 +89,6 @@ class ConvEngine:
                 torch.cuda.synchronize(dev)
             ws = table[key] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=dev)
         return ws
-
-    def _counters(self, L, dev, stream):
-        """Per-tile arrival counters of the one-launch split-K (zero between launches; one set per stream)."""
-        key = (dev, stream, self._capturing(L, stream))
-        c = self._splitk_counters.get(key)
-        if c is None:
-            c = self._splitk_counters[key] = torch.zeros(8192, dtype=torch.int32, device=dev)
-            if not key[2]:
-                torch.cuda.current_stream(dev).synchronize()      # zero-fill done before a side stream uses it
-        return c
 
     def conv(self, L, pc, x, B, H, W, out, relu, stream, res=None, in_ps=None, out_ps=None, res_ps=None,
              x_off=0, out_off=0, res_off=0, splitk=False, splitk_n=0, pre=None):
@@ -175,10 +145,8 @@ class ConvEngine:
             hook("begin", pc, B * Ho * Wo, stream, res is not None, kname)
         if S > 1:     # latency-bound GEMM: deterministic split-K with a per-stream workspace
             ws = self._workspace(L, x.device, stream, L.hands_conv2d_workspace_floats(C.byref(d), S))
-            cnt = self._counters(L, x.device, stream) if self.fuse_splitk_reduce else None
-            check(L.hands_conv2d_nhwc_splitk_fused_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias), rp, ptr(out, out_off),
-                                                       S, ptr(ws), ws.numel(), ptr(cnt), cnt.numel() if cnt is not None else 0,
-                                                       stream), "hands_conv2d_nhwc_splitk_fused_f32")
+            check(L.hands_conv2d_nhwc_splitk_n_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias), rp, ptr(out, out_off),
+                                                   S, ptr(ws), ws.numel(), stream), "hands_conv2d_nhwc_splitk_n_f32")
         elif use_sk:
             key = (x.device, stream)
             sk = self._sk_ws.get(key)
@@ -197,27 +165,6 @@ class ConvEngine:
             hook("end", pc, B * Ho * Wo, stream, res is not None, kname)
         return Ho, Wo
 
-    def expand_ok(self, L, c2, c3, B, H, W):
-        """Can conv2 (3x3 / stride 1) + conv3 (1x1 expand, + identity, ReLU) of one bottleneck run as one launch?"""
-        if not (self.winograd and self.fuse_expand and self.math == "fp32" and c2.wino is not None and c3.w_op is not None
-                and c3.KH == 1 and c3.stride == 1 and c3.pad == 0 and c3.Cin == c2.Cout):
-            return False
-        d = ConvDesc(B, H, W, c2.Cin, H, W, c2.Cout, 3, 3, 1, 1, c2.Cin, c2.Cout, 0, c2.Kpad, 1)
-        return bool(L.hands_bottleneck_wino_expand_supported(C.byref(d), c3.Cout))
-
-    def bottleneck_wino_expand(self, L, c2, c3, t1, t2, ident, out, B, H, W, stream, out_off=0):
-        """t2 = relu(conv2(t1)), out = relu(conv3(t2) + identity) in one launch (resnet.py:140-154)."""
-        d = ConvDesc(B, H, W, c2.Cin, H, W, c2.Cout, 3, 3, 1, 1, c2.Cin, c2.Cout, 0, c2.Kpad, 1)
-        hook = self.hook
-        if hook is not None:
-            self.last_wino_macs = L.hands_conv3x3_winograd_executed_macs(C.byref(d)) + c3.macs_per_pixel * B * H * W
-            hook("begin", _ExpandPC(c2, c3), B * H * W, stream, True, "conv_wino_expand_f32_kernel")
-        check(L.hands_bottleneck_wino_expand_f32(C.byref(d), ptr(t1), ptr(c2.wino), ptr(c2.bias), ptr(t2), ptr(c3.w_op), ptr(c3.bias),
-                                                 c3.Cout, ptr(ident), c3.Cout, ptr(out, out_off), c3.Cout, stream),
-              "hands_bottleneck_wino_expand_f32")
-        if hook is not None:
-            hook("end", _ExpandPC(c2, c3), B * H * W, stream, True, "conv_wino_expand_f32_kernel")
-
     def conv_dual(self, L, pc, split, x, x2, B, Ho, Wo, H2, W2, out, stream, act=1, out_off=0):
         """act(conv3(x) + downsample(x2)) (resnet.py:146-154) with the identity never materialised."""
         K0, K1, stride2 = split
@@ -230,23 +177,6 @@ class ConvEngine:
                                             ptr(out, out_off), stream), "hands_conv1x1_dual_nhwc_f32")
         if hook is not None:
             hook("end", pc, B * Ho * Wo, stream, False, "conv_igemm_f32_kernel")
-
-    @staticmethod
-    def link_ok(c3, c1, npix):
-        """Can conv3 (+identity, ReLU) of one bottleneck and conv1 (ReLU) of the next run as hands_bottleneck_link_f32?"""
-        return (c3.KH == 1 and c3.KW == 1 and c3.stride == 1 and c3.pad == 0 and c3.Cin == 64 and c3.Kpad == 64 and c3.Cout == 256
-                and c1.KH == 1 and c1.KW == 1 and c1.stride == 1 and c1.pad == 0 and c1.Cin == 256 and c1.Kpad == 256
-                and c1.Cout in (64, 128) and npix % 64 == 0)
-
-    def bottleneck_link(self, L, c3, c1, t2, ident, out, t1, npix, stream, out_off=0):
-        """out = relu(conv3(t2) + identity), t1 = relu(conv1(out)) in one launch (resnet.py:146-154 + 137-139)."""
-        hook = self.hook
-        if hook is not None:
-            hook("begin", _LinkPC(c3, c1), npix, stream, True, "bottleneck_link_kernel")
-        check(L.hands_bottleneck_link_f32(ptr(t2), ptr(c3.w), ptr(c3.bias), ptr(ident), ptr(out, out_off), ptr(c1.w), ptr(c1.bias),
-                                          ptr(t1), npix, c1.Cout, stream), "hands_bottleneck_link_f32")
-        if hook is not None:
-            hook("end", _LinkPC(c3, c1), npix, stream, True, "bottleneck_link_kernel")
 
     def stem_pool(self, L, pc, x4, x_off, out, B, H, W, act, stream):
         """conv 7x7/2 + folded BN + act + max-pool 3x3/2 in one kernel (resnet.py:264-268); the conv map
@@ -273,36 +203,6 @@ class ConvEngine:
         if hook is not None:
             hook("end", pc, B * Hc * Wc, stream, False, "stem_pool_planar_kernel")
         return Hc, Wc
-
-
-class _LinkPC:
-    """What bench.py's launch hook reads, for the fused conv3 -> conv1 launch: algorithmic work of BOTH layers."""
-
-    def __init__(self, c3, c1):
-        self.Cin, self.Cout, self.KH, self.KW, self.stride = c3.Cin, c3.Cout, 1, 1, 1
-        self.macs_per_pixel = c3.macs_per_pixel + c1.macs_per_pixel
-        # bytes per pixel: t2 in, identity in, out, t1 out (+ both weight matrices once per launch)
-        self.alg_bytes_per_pixel = 4.0 * (c3.Cin + 2 * c3.Cout + c1.Cout)
-        self.w = _Numel(c3.w.numel() + c1.w.numel())
-
-
-class _ExpandPC:
-    """What bench.py's launch hook reads for the fused conv2 (Winograd) + conv3 launch: algorithmic work of BOTH layers."""
-
-    def __init__(self, c2, c3):
-        self.Cin, self.Cout, self.KH, self.KW, self.stride = c2.Cin, c3.Cout, 3, 3, 1
-        self.macs_per_pixel = c2.macs_per_pixel + c3.macs_per_pixel
-        # bytes per pixel: t1 in, t2 out (still written), identity in, out (+ both weight sets once per launch)
-        self.alg_bytes_per_pixel = 4.0 * (c2.Cin + c2.Cout + 2 * c3.Cout)
-        self.w = _Numel(c2.wino.numel() + c3.w.numel())
-
-
-class _Numel:
-    def __init__(self, n):
-        self._n = n
-
-    def numel(self):
-        return self._n
 
 
 DEFAULT_ENGINE = ConvEngine()

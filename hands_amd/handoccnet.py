@@ -111,6 +111,11 @@ class HandOccNet(EngineSwitches, nn.Module):
         return st
 
     def invalidate_packed(self):
+        # forwards still in flight on the pipeline / side streams read the packed weights: wait for them before the tensors
+        # are dropped (the caching allocator only knows the stream they were allocated on)
+        for ev in self._pipe_done.values():
+            ev.synchronize()
+        self._pipe_done.clear()
         self._packed = None
 
     def _apply(self, fn, *a, **k):

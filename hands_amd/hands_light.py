@@ -31,7 +31,7 @@ from . import _lib
 from ._lib import ManoConsts, ManoOut, ManoSide, check, ptr
 from .engine import DEFAULT_ENGINE, ConvEngine, EngineSwitches
 from .mano import ManoLayer, build_mano_asset
-from .packing import (HMR_VEC, add_operand_form, PackedConv, fold_bn, hmr_state_columns, pack_conv, pack_conv1x1_dual,
+from .packing import (HMR_VEC, PackedConv, fold_bn, hmr_state_columns, pack_conv, pack_conv1x1_dual,
                       pack_linear, pack_mano)
 from .xdict import prefix_dict, stream_xdict, xdict
 
@@ -345,7 +345,7 @@ class HandsLight(EngineSwitches, nn.Module):
                 e = {}
                 w, b = fold_bn(cpu(blk.conv1.weight), *bnp(blk.bn1)); e["c1"] = pack_conv(w, b, 1, 0, dev)
                 w, b = fold_bn(cpu(blk.conv2.weight), *bnp(blk.bn2)); e["c2"] = pack_conv(w, b, blk.stride, 1, dev)
-                w, b = fold_bn(cpu(blk.conv3.weight), *bnp(blk.bn3)); e["c3"] = add_operand_form(pack_conv(w, b, 1, 0, dev))
+                w, b = fold_bn(cpu(blk.conv3.weight), *bnp(blk.bn3)); e["c3"] = pack_conv(w, b, 1, 0, dev)
                 if blk.downsample is not None:
                     w, b = fold_bn(cpu(blk.downsample[0].weight), *bnp(blk.downsample[1]))
                     e["ds"] = pack_conv(w, b, blk.stride, 0, dev)
@@ -453,20 +453,11 @@ class HandsLight(EngineSwitches, nn.Module):
         """A run of bottlenecks (resnet.py:134-154) on ping-pong buffers; the last one writes ``final_dst``
         at float offset ``final_off``.  Returns (H, W) of the output map."""
         n = len(blocks)
-        linked = False          # this block's conv1 was already computed by the previous block's fused launch
         for i, e in enumerate(blocks):
-            if not linked:
-                self.engine.conv(L, e["c1"], cur, B, H, W, t1, True, stream)
+            self.engine.conv(L, e["c1"], cur, B, H, W, t1, True, stream)
             last = i + 1 == n
             dst, off = (final_dst, final_off) if last else (nxt, 0)
-            if "ds" not in e and not self.engine.fuse_link and self.engine.expand_ok(L, e["c2"], e["c3"], B, H, W):
-                # conv2 (Winograd) and conv3 + identity + ReLU in one launch: conv3's HBM traffic under other workgroups' stages
-                self.engine.bottleneck_wino_expand(L, e["c2"], e["c3"], t1, t2, cur, dst, B, H, W, stream, out_off=off)
-                linked = False
-                cur, nxt = dst, cur
-                continue
             H2, W2 = self.engine.conv(L, e["c2"], t1, B, H, W, t2, True, stream)
-            linked = False
             if "ds" in e and self.engine.fuse_downsample:
                 self.engine.conv_dual(L, e["c3ds"], e["c3ds_split"], t2, cur, B, H2, W2, H, W, dst, stream, out_off=off)
             else:
@@ -475,14 +466,7 @@ class HandsLight(EngineSwitches, nn.Module):
                     ident = ds
                 else:
                     ident = cur
-                if (not last and self.engine.fuse_link and self.engine.math == "fp32" and "ds" not in e
-                        and self.engine.link_ok(e["c3"], blocks[i + 1]["c1"], B * H2 * W2)):
-                    # conv3 + identity + ReLU, and the NEXT block's conv1 + ReLU on the tile while it is still in LDS
-                    # (t1 is free: this block's conv2 has consumed it, in stream order)
-                    self.engine.bottleneck_link(L, e["c3"], blocks[i + 1]["c1"], t2, ident, dst, t1, B * H2 * W2, stream, out_off=off)
-                    linked = True
-                else:
-                    self.engine.conv(L, e["c3"], t2, B, H2, W2, dst, True, stream, res=ident, out_off=off)
+                self.engine.conv(L, e["c3"], t2, B, H2, W2, dst, True, stream, res=ident, out_off=off)
             H, W = H2, W2
             cur, nxt = dst, cur
         return H, W

@@ -38,8 +38,6 @@ class PackedConv:
     Kpad: int
     macs_per_pixel: int = 0   # ALGORITHMIC multiply-accumulates per output pixel (true, unpadded dims)
     wino: torch.Tensor = None  # 3x3 / stride 1 / pad 1 layers: Winograd F(2x2,3x3) weights (hands_pack_conv3x3_winograd_f64)
-    w_op: torch.Tensor = None  # 1x1 layers that may run as the expand phase of hands_bottleneck_wino_expand_f32: the same
-                               # weight in MFMA operand order (hands_pack_conv1x1_operand_f32), made by add_operand_form()
 
 
 def _f64(t):
@@ -92,16 +90,6 @@ def pack_conv(w, bias, stride, pad, device, cin_pad_to=None, winograd=True) -> P
             up = np.empty(n, np.float32)
             check(L.hands_pack_conv3x3_winograd_f64(Cout, Cin, _p(wn), _p(up)), "hands_pack_conv3x3_winograd_f64")
             pc.wino = torch.from_numpy(up).to(device)
-    return pc
-
-
-def add_operand_form(pc: PackedConv) -> PackedConv:
-    """Attach the MFMA-operand-ordered copy of a 1x1 layer's packed weight (a permutation: same bits)."""
-    if pc.KH == 1 and pc.KW == 1 and pc.Cout % 32 == 0 and pc.Cin % 8 == 0 and pc.w_op is None:
-        wp = np.ascontiguousarray(pc.w.detach().cpu().numpy())
-        wo = np.empty(pc.Cout * pc.Cin, np.float32)
-        check(_lib.lib().hands_pack_conv1x1_operand_f32(pc.Cout, pc.Cin, pc.Kpad, _p(wp), _p(wo)), "hands_pack_conv1x1_operand_f32")
-        pc.w_op = torch.from_numpy(wo).to(pc.w.device)
     return pc
 
 

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define HANDS_EINVAL 10001
-#define HANDS_ABI_VERSION 1
+#define HANDS_ABI_VERSION 2
 
 typedef void* hands_stream_t;
 
@@ -98,30 +98,6 @@ long long hands_conv3x3_winograd_executed_macs(const hands_conv_desc* d);
 int hands_conv3x3_winograd_f32(const hands_conv_desc* d, const float* in, const float* u_packed, const float* bias,
                                float* out, hands_stream_t stream);
 
-/* conv2 (3x3 / stride 1, Winograd) + bn2 + relu -> conv3 (1x1 expand) + bn3 + identity + relu of a stride-1 Bottleneck
- * without a downsample branch (src/nets/backbone/resnet.py:140-154) in ONE launch (csrc/conv_wino.hip, expand phase): the
- * workgroup that produced 128 pixels of t2 reads them back from L2 as the operand of conv3, so conv3's identity reads and
- * output writes (an HBM-bound launch of their own, 77 TFLOP/s) overlap the Winograd stages of the CU's other workgroups.
- * `d` describes conv2 as for hands_conv3x3_winograd_f32 with d->Cout = 64 and act = RELU; t2 (pixel stride
- * d->out_pix_stride) is still written.  `w3_operand` = hands_pack_conv1x1_operand_f32 of conv3's packed weight, `bias3` its
- * bias; identity / out are (B, H, W, Cout3).  Same bits as hands_conv3x3_winograd_f32 followed by hands_conv2d_nhwc_f32
- * (residual = identity, RELU).  hands_bottleneck_wino_expand_supported() returns 1 when the pair can take this route. */
-int hands_bottleneck_wino_expand_supported(const hands_conv_desc* d, int Cout3);
-int hands_bottleneck_wino_expand_f32(const hands_conv_desc* d, const float* in, const float* u_packed, const float* bias2,
-                                     float* t2, const float* w3_operand, const float* bias3, int Cout3,
-                                     const float* identity, int id_pix_stride, float* out, int out_pix_stride,
-                                     hands_stream_t stream);
-
-/* The seam between two bottlenecks of layer1 as ONE launch (csrc/bottleneck_link.hip):
- *     out = relu(conv3_1x1(t2) + bn3 + identity)     src/nets/backbone/resnet.py:146-154 of block i     (64 -> 256)
- *     t1  = relu(conv1_1x1(out) + bn1)               src/nets/backbone/resnet.py:137-139 of block i + 1 (256 -> C1)
- * t2 (M,64), identity / out (M,256), t1 (M,C1), all NHWC with the channel count as pixel stride; w3_packed / bias3 and
- * w1_packed / bias1 are hands_pack_conv_f64 outputs of the two layers (BatchNorm folded).  M % 64 == 0, C1 in {64, 128}.
- * `out` never comes back from HBM for the second product.  Bit-identical to hands_conv2d_nhwc_f32 called twice. */
-int hands_bottleneck_link_f32(const float* t2, const float* w3_packed, const float* bias3, const float* identity,
-                              float* out, const float* w1_packed, const float* bias1, float* t1, long long M, int C1,
-                              hands_stream_t stream);
-
 /* Deterministic split-K form of the same layer for latency-bound GEMMs (1x1 / linear layers with few
  * rows and a long K: the HMR / decoder / regressor heads).  hands_conv2d_splitk_factor() returns the
  * number of K slices S the library would use (1 = no split): S = min(8, Kpad/256) for linear layers
@@ -152,15 +128,6 @@ int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const float* in, co
 int hands_conv2d_nhwc_pre_f32(const hands_conv_desc* desc, const float* in, const float* pre_scale, const float* pre_shift,
                               const float* w_packed, const float* bias, const float* residual, float* out, int S,
                               float* workspace, long long workspace_floats, hands_stream_t stream);
-
-/* The same split-K as ONE launch: `counters` (>= one int per output tile of the launch: ceil(M/128)*ceil(Cout/128), or
- * ceil(M/256) for Cout <= 64; zero before the first use, left zero by every launch) lets the LAST slice of a tile to
- * arrive add the S partial tiles in ascending slice order and apply bias / residual / activation -- exactly the
- * arithmetic of the two-pass form, so the output bits are identical and independent of the arrival order.  A workspace
- * and its counters belong to one stream at a time.  counters == NULL or too few: the two-pass form. */
-int hands_conv2d_nhwc_splitk_fused_f32(const hands_conv_desc* desc, const float* in, const float* w_packed,
-                                       const float* bias, const float* residual, float* out, int S, float* workspace,
-                                       long long workspace_floats, int* counters, int n_counters, hands_stream_t stream);
 
 /* Stream-K form of hands_conv2d_nhwc_f32 for launches whose tile count quantises badly on the chip (400-1600
  * tiles on 256 CUs leave 12-24 % of it idle): G persistent workgroups take equal shares of the (tile, k-step)
@@ -522,9 +489,6 @@ int hands_pack_mano_f32(const float* v_template, const float* shapedirs, const f
 long long hands_conv2d_workspace_floats(const hands_conv_desc* d, int S);
 long long hands_pack_conv3x3_winograd_floats(int Cout, int Cin);
 int hands_pack_conv3x3_winograd_f64(int Cout, int Cin, const double* w_oihw, float* u_packed);
-/* 1x1 weight [Cout_pad][Kpad] (hands_pack_conv_f64) -> MFMA operand order [Cout/32][Cin/8][lane 64][4] (Cout * Cin floats)
- * for the expand phase of hands_bottleneck_wino_expand_f32; a permutation, no arithmetic. */
-int hands_pack_conv1x1_operand_f32(int Cout, int Cin, int Kpad, const float* w_packed, float* w_operand);
 
 #ifdef __cplusplus
 }

@@ -721,31 +721,6 @@ def test_forward_vs_golden(golden_dir, gpu_model, bz, seed):
         assert mp < 1e-3, mp          # "MPJPE vs ref" of the north star, mm
 
 
-def test_forward_with_and_without_the_fused_expand_is_bit_identical(gpu_model):
-    """engine.fuse_expand (layer1's conv2 + conv3 as hands_bottleneck_wino_expand_f32) changes launches, not bits."""
-    inputs, meta = synthetic_inputs(3, 5, device=DEV)
-    seen = []
-    gpu_model.conv_hook = lambda phase, pc, npix, st, has_res, kernel: seen.append(kernel)
-    gpu_model.overlap_trunks = False
-    try:
-        assert gpu_model.engine.fuse_expand is False                # opt-in (measured neutral)
-        gpu_model.engine.fuse_expand = True
-        a = {k: v.clone() for k, v in gpu_model(inputs, meta).items()}
-        n_fused = seen.count("conv_wino_expand_f32_kernel")
-        gpu_model.engine.fuse_expand = False
-        seen.clear()
-        b = {k: v.clone() for k, v in gpu_model(inputs, meta).items()}
-        assert n_fused > 0 and n_fused % 4 == 0 and "conv_wino_expand_f32_kernel" not in seen    # 2 blocks of layer1 per trunk job
-    finally:
-        gpu_model.engine.fuse_expand = False
-        gpu_model.conv_hook = None
-        gpu_model.overlap_trunks = True
-    torch.cuda.synchronize()
-    assert sorted(a) == sorted(b)
-    for k in a:
-        assert torch.equal(a[k], b[k]), k
-
-
 def test_forward_with_the_direct_3x3_kernel_vs_golden(golden_dir, gpu_model):
     """engine.winograd = False: the 3x3 / stride-1 layers on the direct implicit GEMM again (the route of rounds 1-2) --
     same golden bar, and within fp32 re-association noise of the default (Winograd) forward."""
@@ -961,53 +936,7 @@ def test_wrapper_inference_contract(gpu_model):
     assert sum(k.startswith("pred.") for k in out) == 22
 
 
-@pytest.mark.parametrize("C1", [64, 128])
-@pytest.mark.parametrize("B", [2, 37])
-def test_bottleneck_link_is_bit_identical(C1, B):
-    """hands_bottleneck_link_f32: relu(conv3(t2) + identity) and the NEXT bottleneck's relu(conv1(.)) in one launch
-    (resnet.py:146-154 + 137-139) == the two hands_conv2d_nhwc_f32 launches, bit for bit, and right against fp64."""
-    L = _lib.lib()
-    H = 8 if B == 2 else 56                      # M = B * H * H: 128 pixels (2 tiles) / 116 032 (more tiles than workgroups)
-    g = torch.Generator().manual_seed(C1 + B)
-    w3 = torch.randn(256, 64, 1, 1, generator=g) / 8
-    w1 = torch.randn(C1, 256, 1, 1, generator=g) / 16
-    c3 = pack_conv(w3, torch.randn(256, generator=g), 1, 0, DEV)
-    c1 = pack_conv(w1, torch.randn(C1, generator=g), 1, 0, DEV)
-    t2 = torch.randn(B, H, H, 64, generator=g).to(DEV)
-    ident = torch.randn(B, H, H, 256, generator=g).to(DEV)
-    eng = ConvEngine()
-    M = B * H * H
-    assert eng.link_ok(c3, c1, M)
-    out_a, t1_a = torch.full((M, 256), float("nan"), device=DEV), torch.full((M, C1), float("nan"), device=DEV)
-    eng.conv(L, c3, t2, B, H, H, out_a, True, _stream(), res=ident)
-    eng.conv(L, c1, out_a, B, H, H, t1_a, True, _stream())
-    out_b, t1_b = torch.full((M, 256), float("nan"), device=DEV), torch.full((M, C1), float("nan"), device=DEV)
-    eng.bottleneck_link(L, c3, c1, t2, ident, out_b, t1_b, M, _stream())
-    torch.cuda.synchronize()
-    assert torch.equal(out_a, out_b) and torch.equal(t1_a, t1_b)
-    x64 = t2.cpu().double().view(M, 64)
-    o64 = F.relu(x64 @ w3.double().view(256, 64).T + c3.bias[:256].cpu().double() + ident.cpu().double().view(M, 256))
-    t64 = F.relu(o64 @ w1.double().view(C1, 256).T + c1.bias[:C1].cpu().double())
-    assert (out_b.cpu().double() - o64).abs().max().item() < 2e-5 * max(1.0, o64.abs().max().item())
-    assert (t1_b.cpu().double() - t64).abs().max().item() < 2e-5 * max(1.0, t64.abs().max().item())
-    # refused shapes fall back to the two launches in the model (engine.link_ok): the entry point itself says EINVAL
-    assert L.hands_bottleneck_link_f32(ptr(t2), ptr(c3.w), ptr(c3.bias), ptr(ident), ptr(out_b), ptr(c1.w), ptr(c1.bias),
-                                       ptr(t1_b), M - 1, C1, _stream()) != 0
-
-
-def test_forward_with_and_without_the_fused_seam_is_bit_identical(gpu_model):
-    inputs, meta_info = synthetic_inputs(3, 9, device=DEV)
-    a = {k: v.clone() for k, v in gpu_model(inputs, meta_info).items()}
-    gpu_model.engine.fuse_link = True            # opt-in (measured slower than the separate launches: engine.py)
-    try:
-        b = {k: v.clone() for k, v in gpu_model(inputs, meta_info).items()}
-    finally:
-        gpu_model.engine.fuse_link = False
-    for k in a:
-        assert torch.equal(a[k], b[k]), k
-
-
-SPLITK_FUSED_CASES = [
+SPLITK_CASES = [
     # B, Cin, H, W, Cout, k, stride, pad, act, residual, S
     (64, 128, 8, 8, 128, 3, 1, 1, 3, False, 4),      # handoccnet hourglass level (LeakyReLU), 32 tiles x 4 slices
     (64, 256, 4, 4, 128, 1, 1, 0, 3, True, 2),       # pointwise + residual
@@ -1018,11 +947,10 @@ SPLITK_FUSED_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", SPLITK_FUSED_CASES)
-def test_splitk_reduce_in_the_launch_is_bit_identical(case):
-    """hands_conv2d_nhwc_splitk_fused_f32 (the last slice of a tile to arrive reduces it) == the two-pass
-    hands_conv2d_nhwc_splitk_n_f32 bit for bit -- the additions run in slice order, never in arrival order --, is
-    reproducible over repeated launches and leaves its counters zero."""
+@pytest.mark.parametrize("case", SPLITK_CASES)
+def test_splitk_n_is_deterministic_and_right(case):
+    """hands_conv2d_nhwc_splitk_n_f32 (call-site slice count S; partial sums reduced in slice order by splitk_reduce_kernel):
+    reproducible bit for bit over repeated launches and fresh engines, and right against an fp64 convolution."""
     B, Cin, H, W, Cout, k, stride, pad, act, use_res, S = case
     L = _lib.lib()
     g = torch.Generator().manual_seed(sum(case))
@@ -1032,18 +960,15 @@ def test_splitk_reduce_in_the_launch_is_bit_identical(case):
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     res = torch.randn(B, Ho, Wo, pc.Cout, generator=g).to(DEV) if use_res else None
     outs = {}
-    for fused in (False, True, True):
+    for rep in (False, True):
         eng = ConvEngine()
-        eng.fuse_splitk_reduce = fused
         out = torch.full((B, Ho, Wo, pc.Cout), float("nan"), device=DEV)
-        for _ in range(3 if fused else 1):
+        for _ in range(3 if rep else 1):
             eng.conv(L, pc, x, B, H, W, out, act, _stream(), res=res, splitk_n=S)
         torch.cuda.synchronize()
-        if fused:
-            cnt = next(iter(eng._splitk_counters.values()))
-            assert int(cnt.abs().sum().item()) == 0
+        if rep:
             assert torch.equal(out, outs[False])
-        outs[fused] = out.clone()
+        outs[rep] = out.clone()
     ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double(), pc.bias[:Cout].double().cpu(), stride=stride, padding=pad)
     if res is not None:
         ref = ref + res.permute(0, 3, 1, 2)[:, :Cout].double().cpu()

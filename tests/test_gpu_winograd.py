@@ -191,39 +191,3 @@ def test_winograd_full_size_against_the_direct_kernel(shape):
     torch.cuda.synchronize()
     b = pc.bias[:Cch].view(1, 1, 1, Cch)
     assert (y12 + b - y1 - y2).abs().max().item() <= 3e-5 * y12.abs().max().item()
-
-
-@pytest.mark.parametrize("geom", [(3, 56, 56, 256), (5, 28, 28, 256), (7, 14, 14, 128), (9, 7, 7, 256), (2, 9, 11, 64), (33, 8, 8, 32)])
-def test_bottleneck_wino_expand_is_bit_identical_to_the_two_launches(geom):
-    """hands_bottleneck_wino_expand_f32: conv2 (3x3 Winograd, 64 planes) + relu and conv3 (1x1 expand) + identity + relu in one
-    launch must reproduce hands_conv3x3_winograd_f32 followed by hands_conv2d_nhwc_f32 bit for bit (t2 and out), for every
-    block geometry, odd maps and partial blocks."""
-    from hands_amd.packing import add_operand_form
-    B, H, W, C3 = geom
-    L = _lib.lib()
-    g = torch.Generator().manual_seed(B * 1000 + H)
-    Cm = 64
-    w2 = torch.randn(Cm, Cm, 3, 3, generator=g) / (Cm * 9) ** 0.5
-    w3 = torch.randn(C3, Cm, 1, 1, generator=g) / Cm ** 0.5
-    c2 = pack_conv(w2, torch.randn(Cm, generator=g), 1, 1, DEV)
-    c3 = add_operand_form(pack_conv(w3, torch.randn(C3, generator=g), 1, 0, DEV))
-    t1 = torch.randn(B, H, W, Cm, generator=g).to(DEV)
-    ident = torch.randn(B, H, W, C3, generator=g).to(DEV)
-    eng = ConvEngine()
-    eng.fuse_expand = True                      # opt-in (measured neutral against the two launches)
-    assert eng.expand_ok(L, c2, c3, B, H, W)
-    t2a = torch.full((B, H, W, Cm), float("nan"), device=DEV)
-    oa = torch.full((B, H, W, C3), float("nan"), device=DEV)
-    eng.bottleneck_wino_expand(L, c2, c3, t1, t2a, ident, oa, B, H, W, _stream())
-    t2b = torch.full((B, H, W, Cm), float("nan"), device=DEV)
-    ob = torch.full((B, H, W, C3), float("nan"), device=DEV)
-    eng.conv(L, c2, t1, B, H, W, t2b, True, _stream())
-    sep = ConvEngine()
-    sep.stream_k = False
-    sep.conv(L, c3, t2b, B, H, W, ob, True, _stream(), res=ident)
-    torch.cuda.synchronize()
-    assert torch.isfinite(oa).all() and torch.equal(t2a, t2b)
-    assert torch.equal(oa, ob)
-    ref = F.relu(F.conv2d(F.relu(F.conv2d(t1.cpu().permute(0, 3, 1, 2).double(), w2.double(), c2.bias[:Cm].cpu().double(), padding=1)),
-                          w3.double(), c3.bias[:C3].cpu().double()) + ident.cpu().permute(0, 3, 1, 2).double())
-    assert (oa.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
