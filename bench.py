@@ -63,6 +63,9 @@ def parse_args(argv=None):
                     help="time the one-stream mode as the headline too (every launch alone on the chip)")
     ap.add_argument("--latency-mode", action="store_true",
                     help="small-batch serving mode: split-K on every launch with <= 128 output tiles")
+    ap.add_argument("--graph", type=int, default=0, metavar="DEPTH",
+                    help="replay the forward as a hipGraph (hands_amd.GraphedForward); DEPTH=2 keeps two captured instances "
+                         "in flight (handoccnet_light only)")
     ap.add_argument("--layer-report", default="", help="write a per-launch CSV of the MFMA kernels here")
     return ap.parse_args(argv)
 
@@ -354,7 +357,7 @@ def forward_with_d2h_ms(ctx, model, inputs, meta, n):
 
 
 def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False, parity_bz=0, layer_report="", math="fp32",
-                  winograd=None, winograd_scope=None):
+                  winograd=None, winograd_scope=None, graph=0):
     """Returns (result dict, model, cpu state_dict) -- result holds value / ms_per_step / roofline / serial /
     overlapped (+ parity vs the oracle on ``parity_bz`` samples when > 0, rank 0 only)."""
     torch = ctx.torch
@@ -394,9 +397,10 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
     if workload == "hands_light" and os.environ.get("HANDS_CHUNKS"):
         model.trunk_chunks = tuple(int(v) for v in os.environ["HANDS_CHUNKS"].split(","))
     inputs, meta = hands_amd.synthetic_inputs(bz, seed=ctx.rank, device=ctx.dev)
+    fwd = hands_amd.GraphedForward(model, inputs, meta, depth=graph) if graph else model
 
     def step():
-        out = model(inputs, meta)
+        out = fwd(inputs, meta)
         if ctx.host_collective:                   # dry-run only: gloo gathers host tensors
             torch.cuda.synchronize(ctx.dev)
             return gather_predictions({k: v.cpu() for k, v in out.items()})
@@ -882,7 +886,7 @@ def main():
     else:
         want_parity = first and not args.no_cpu_baseline and ctx.world == 1
         res, model, sd_cpu = measure_model(ctx, wl, bz, args.steps, args.warmup, args, serial_headline=args.serial,
-                                           parity_bz=8 if want_parity else 0, layer_report=args.layer_report)
+                                           parity_bz=8 if want_parity else 0, layer_report=args.layer_report, graph=args.graph)
     if rank0:
         cpu_baseline, parity = res.pop("cpu_baseline", None), res.pop("parity", None)
         if wl != "mano_lbs" and not args.no_cpu_baseline and ctx.world == 1:
@@ -902,7 +906,8 @@ def main():
                        "rccl_ranks": ctx.rccl_ranks, "collective_backend": ctx.backend if ctx.world > 1 else None,
                        "launched_by": "bench.py launcher" if os.environ.get("HANDS_BENCH_LAUNCHED") else
                                       ("torchrun" if ctx.world > 1 else "direct"),
-                       "timed_mode": "serial" if args.serial else "multi-stream", "latency_mode": bool(args.latency_mode),
+                       "timed_mode": ("serial" if args.serial else "multi-stream") + (f"+hipgraph(depth={args.graph})" if args.graph else ""),
+                       "latency_mode": bool(args.latency_mode),
                        "cpu_affinity": CPU_PIN.get("note"), "conv3x3_stride1": conv3x3_route(model)},
             "cpu_baseline": cpu_baseline, "parity": parity})
 
@@ -920,25 +925,29 @@ def main():
         # *_winograd_all: HandOccNet's opt-in scope
         for name, abz, asteps, awarm, pbz in (("hands_light_bf16x3", 256, 10, 3, 8), ("hamer_light", 64, 4, 1, 1),
                                               ("hamer_light_bf16x3", 64, 4, 1, 1), ("handoccnet_light", 32, 10, 3, 2),
+                                              ("handoccnet_light_graph2", 32, 10, 3, 2),
                                               ("handoccnet_light_winograd_all", 32, 10, 3, 2)):
             key = name
             try:
-                math, wino, wscope = "fp32", None, None
+                math, wino, wscope, graph = "fp32", None, None, 0
+                if name.endswith("_graph2"):        # hands_amd.GraphedForward(depth=2): two captured forwards in flight
+                    name, graph = name[: -len("_graph2")], 2
                 if name.endswith("_winograd_all"):
                     name, wino, wscope = name[: -len("_winograd_all")], True, "all"
                 if name.endswith("_bf16x3"):
                     name, math = name[: -len("_bf16x3")], "bf16x3"
                 r, m, sd = measure_model(ctx, name, abz, asteps, awarm, args, parity_bz=pbz, math=math, winograd=wino,
-                                         winograd_scope=wscope)
+                                         winograd_scope=wscope, graph=graph)
                 r.update(metric="hands/sec", unit="hands/s", n_gpus=1, steps=asteps, warmup=awarm, dtype="f32", math=math)
-                if math == "fp32" and name != "hands_light" and not args.no_cpu_baseline and not wino:
+                if math == "fp32" and name != "hands_light" and not args.no_cpu_baseline and not wino and not graph:
                     r["cpu_baseline"], r["parity"] = cpu_baseline_small(ctx, name, m, sd, pbz)
                     if not args.no_sweep:
                         r["parity"].update(parity_sweep(ctx, name, m, sd))
                 else:
                     r["parity"] = parity_vs_oracle(ctx, name, m, sd, pbz)
                 r["config"] = {"workload": workload_text(name, abz, 1), "per_gpu_batch": abz, "global_batch": abz,
-                               "conv3x3_stride1": conv3x3_route(m)}
+                               "conv3x3_stride1": conv3x3_route(m),
+                               "timed_mode": "multi-stream" + (f"+hipgraph(depth={graph})" if graph else "")}
                 emit_also(key, r)
                 del m, sd
                 torch.cuda.empty_cache()

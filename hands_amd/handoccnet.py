@@ -58,6 +58,8 @@ def _conv_fns(L, stream, new, engine, small_map_splitk=True):
 
 
 class HandOccNet(EngineSwitches, nn.Module):
+    graph_private_buffers = True    # forward allocates every activation per call: GraphedForward(depth=2) is safe
+
     def __init__(self, focal_length=1000.0, img_res=224, args=None, mano_assets=None):
         super().__init__()
         args = args if args is not None else HANDOCC_DEFAULT_ARGS
@@ -257,8 +259,8 @@ class HandOccNet(EngineSwitches, nn.Module):
         center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
         corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0)
         dbg = self.__dict__.get("_debug")
-        pipelined = bool(self.async_forward and self.engine.overlap and dbg is None and self.engine.hook is None
-                         and not self.engine._capturing(L, main.cuda_stream))
+        capturing = self.engine._capturing(L, main.cuda_stream)
+        pipelined = bool(self.async_forward and self.engine.overlap and dbg is None and self.engine.hook is None and not capturing)
         if pipelined:
             par = self._calls % max(1, int(self.pipeline_depth))
             self._calls += 1
@@ -271,8 +273,9 @@ class HandOccNet(EngineSwitches, nn.Module):
                 t.record_stream(st)
         else:
             st = main
-            for evd in self._pipe_done.values():     # a synchronous call is ordered after every forward still in flight
-                main.wait_event(evd)
+            if not capturing:                        # (GraphedForward drains the device before it captures)
+                for evd in self._pipe_done.values():     # a synchronous call is ordered after every forward still in flight
+                    main.wait_event(evd)
         with torch.cuda.stream(st):
             output = self._forward_body(L, P, dev, x4, center, corner, K, bz)
         if not pipelined:

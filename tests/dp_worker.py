@@ -37,6 +37,21 @@ def main():
         if hi > lo:
             assert dev in dist_mod._gather_streams, "the stream-ordered gather path was not taken"
             assert isinstance(got, stream_xdict) and got.is_pending
+        # the gathered, still-pending dict is first READ ON A THIRD STREAM while the next forward
+        # (+ its gather) is already enqueued -- the buffers `full` / `flat` of dist.gather_predictions were allocated on
+        # the gather side stream and reach the consumer only through stream_xdict's wait_event + record_stream.
+        # (Every rank issues the same collectives.)
+        flipped = {k: (v.flip(0) if torch.is_tensor(v) and v.ndim else v) for k, v in inputs.items()}
+        nxt = data_parallel_forward(model, flipped, meta, gather_on_host=False)
+        third = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(third):
+            snap = {k: v.clone() for k, v in got.items()}                    # joins on `third`
+            junk = [torch.empty_like(v).normal_() for v in snap.values()]    # allocator churn on the consumer stream
+        del got, junk, nxt
+        for _ in range(3):                                                   # later forwards re-use the freed blocks
+            data_parallel_forward(model, inputs, meta, gather_on_host=False)
+        torch.cuda.synchronize(dev)
+        got = snap
     if rank == 0:
         torch.save({k: v.detach().cpu().clone() for k, v in got.items()}, out_path)
     dist.barrier()

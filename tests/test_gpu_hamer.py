@@ -183,3 +183,20 @@ def test_hamer_full_size_batch_independence_and_parity(hamer_gpu):
         verr = (big[f"mano.vertices.{hn}"][bz - 1:].cpu() - ref[f"mano.vertices.{hn}"]).abs().max().item()
         mp = O.mpjpe_ra_mm(big[f"mano.joints3d.{hn}"][bz - 1:].cpu(), ref[f"mano.joints3d.{hn}"])
         assert verr < 1e-6 and mp < 1e-3, (hn, verr, mp)
+
+
+def test_graphed_hamer_is_bit_identical(hamer_gpu):
+    """hipGraph replay of HAMER.forward (src/models/hamer_light/model.py:75-151; two crop chunks on two streams, fork / join
+    events included) == the eager call bit for bit, also on new inputs copied into the captured buffers."""
+    from hands_amd import GraphedForward
+    samples = [synthetic_inputs(2, seed, device=DEV) for seed in (0, 4)]
+    eager = [{k: v.clone() for k, v in hamer_gpu(i, m).items()} for i, m in samples]
+    torch.cuda.synchronize()
+    gf = GraphedForward(hamer_gpu, *samples[0])
+    for (inputs, meta_info), ref in zip(samples, eager):
+        got = gf(inputs, meta_info)
+        torch.cuda.synchronize()
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), k
+    with pytest.raises(ValueError):           # persistent workspaces: one captured instance at a time
+        GraphedForward(hamer_gpu, *samples[0], depth=2)

@@ -240,3 +240,42 @@ def test_handoccnet_forward_is_bit_identical_without_the_folded_preactivation(ho
         hon_gpu.engine.fuse_pre = True
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("bz", [2, 32])
+def test_graphed_handoccnet_is_bit_identical(hon_gpu, bz):
+    """hipGraph replay of HandOccNet.forward (model.py:60-129) == the eager call bit for bit: one captured instance, and
+    TWO instances in flight (depth=2, the pipelined mode of the 8-GPU shard size: call i replayed on stream i & 1, joined
+    at first use), on new inputs copied into the captured buffers, with the caller overwriting its inputs right after
+    every call."""
+    from hands_amd import GraphedForward
+    samples = [synthetic_inputs(bz, seed, device=DEV) for seed in (0, 3, 5, 9)]
+    eager = []
+    for inputs, meta_info in samples:
+        eager.append({k: v.clone() for k, v in hon_gpu(inputs, meta_info).items()})
+    torch.cuda.synchronize()
+    g1 = GraphedForward(hon_gpu, *samples[0])
+    for (inputs, meta_info), ref in zip(samples, eager):
+        got = g1(inputs, meta_info)
+        torch.cuda.synchronize()
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), (bz, k)
+    g2 = GraphedForward(hon_gpu, *samples[0], depth=2)
+    outs = []
+    for (inputs, meta_info), ref in zip(samples, eager):
+        mine = ({k: v.clone() for k, v in inputs.items()}, {k: v.clone() for k, v in meta_info.items()})
+        out = g2(*mine)
+        for d in mine:                      # the caller may overwrite its inputs as soon as the call returns
+            for v in d.values():
+                v.zero_()
+        assert out.is_pending
+        outs.append({k: v.clone() for k, v in out.items()})       # joins on the current stream; clone before reuse
+    torch.cuda.synchronize()
+    for got, ref in zip(outs, eager):
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), (bz, k)
+    bad = synthetic_inputs(bz + 1, 0, device=DEV)
+    with pytest.raises(ValueError):
+        g2(*bad)
+    with pytest.raises(ValueError):         # persistent-workspace models cannot have two captured instances in flight
+        GraphedForward(hands_amd.HandsLight(), *samples[0], depth=2)
