@@ -71,6 +71,8 @@ SIGNATURES = {
     "hands_nchw3_to_nhwc4_f32": [_P, _P, _I, _I, _I, _P],
     "hands_maxpool3x3s2_nhwc_f32": [_P, _P, _I, _I, _I, _I, _P],
     "hands_sumpool_nhwc_f32": [_P, _P, _I, _I, _I, _I, _P],
+    "hands_avgpool_nhwc_f32": [_P, _P, _I, _I, _I, _I, _P],
+    "hands_image_posenc_nhwc_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hands_kpe_concat_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "hands_hmr_init_f32": [_P, _P, _I, _I, _I, _P],
     "hands_rot6d_to_matrix_f32": [_P, _I, _P, _I, _P],

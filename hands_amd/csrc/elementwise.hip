@@ -66,6 +66,23 @@ __global__ void sumpool_kernel(const float4* __restrict__ in, float* __restrict_
   }
 }
 
+// ---- feat[b,c] = (sum_p feat[b,p,c]) / HW: nn.AdaptiveAvgPool2d(1) of HandHMR.forward(use_pool=True) (hand_hmr.py:73-78),
+//      the `no_crops` route of model.py:316-318 (arctic_light).  Same sequential sum as sumpool_kernel, then one division.
+__global__ void avgpool_kernel(const float4* __restrict__ in, float* __restrict__ out, int B, int HW, int C4, int out_stride) {
+  const int total = B * C4;
+  const float n = (float)HW;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int b = i / C4, c = i - b * C4;
+    const float4* src = in + (long long)b * HW * C4 + c;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < HW; ++p) {
+      const float4 v = src[(long long)p * C4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + (long long)b * out_stride + c * 4) = make_float4(s.x / n, s.y / n, s.z / n, s.w / n);
+  }
+}
+
 // ---- cat([crop+glb, center_enc, corner_enc]) ------------------------------------------------------
 // encoding element e of an angle vector with nc components: layout (L, nc, 2): k = e/(2nc),
 // ci = (e/2)%nc, sc = e&1 -> sin/cos(2^k * angle[ci])            (model.py:444-460)
@@ -103,6 +120,33 @@ __global__ void kpe_concat_kernel(const float4* __restrict__ crop, const float4*
       v = make_float4(r[0], r[1], r[2], r[3]);
     }
     out[i] = v;
+  }
+}
+
+// ---- image-level positional encodings (pos_enc = 'center' | 'corner' | 'center+corner', model.py:203-218): the crop image
+//      with the per-sample encoding repeated over every pixel as extra input channels, written as the NHWC tensor
+//      (B, H, W, Cpad) the general convolution reads: [r g b | center enc (4 L) | corner enc (16 L) | zeros].
+//      mode bit 0: center, bit 1: corner.
+__global__ void image_posenc_kernel(const float* __restrict__ img, const float* __restrict__ center,
+                                    const float* __restrict__ corner, float4* __restrict__ out, int B, int HW, int L, int mode,
+                                    int Cp4) {
+  const int nce = (mode & 1) ? 4 * L : 0, nco = (mode & 2) ? 16 * L : 0;
+  const long long total = (long long)B * HW * Cp4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % Cp4);
+    const long long pix = i / Cp4;
+    const int b = (int)(pix / HW);
+    const int p = (int)(pix - (long long)b * HW);
+    float r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ch = c4 * 4 + u;
+      if (ch < 3) r[u] = img[((long long)b * 3 + ch) * HW + p];
+      else if (ch < 3 + nce) r[u] = kpe_elem(center + b * 2, 2, ch - 3);
+      else if (ch < 3 + nce + nco) r[u] = kpe_elem(corner + b * 8, 8, ch - 3 - nce);
+      else r[u] = 0.f;
+    }
+    out[i] = make_float4(r[0], r[1], r[2], r[3]);
   }
 }
 
@@ -235,6 +279,26 @@ int hands_sumpool_nhwc_f32(const float* feat, float* out, int B, int HW, int C, 
   if (!feat || !out || B <= 0 || C % 4 || out_stride % 4) return HANDS_EINVAL;
   hipLaunchKernelGGL(sumpool_kernel, dim3(hands_grid_1d((long long)B * C / 4, 64)), dim3(64), 0,
                      (hipStream_t)stream, (const float4*)feat, out, B, HW, C / 4, out_stride);
+  HANDS_LAUNCH_CHECK();
+}
+
+int hands_avgpool_nhwc_f32(const float* feat, float* out, int B, int HW, int C, int out_stride,
+                           hands_stream_t stream) {
+  if (!feat || !out || B <= 0 || HW <= 0 || C % 4 || out_stride % 4) return HANDS_EINVAL;
+  hipLaunchKernelGGL(avgpool_kernel, dim3(hands_grid_1d((long long)B * C / 4, 64)), dim3(64), 0,
+                     (hipStream_t)stream, (const float4*)feat, out, B, HW, C / 4, out_stride);
+  HANDS_LAUNCH_CHECK();
+}
+
+int hands_image_posenc_nhwc_f32(const float* img_nchw, const float* center_angle, const float* corner_angle, float* out,
+                                int B, int H, int W, int n_freq, int mode, int Cpad, hands_stream_t stream) {
+  if (!img_nchw || !out || B <= 0 || H <= 0 || W <= 0 || n_freq < 1 || n_freq > 16 || mode < 1 || mode > 3 || Cpad % 4)
+    return HANDS_EINVAL;
+  if (((mode & 1) && !center_angle) || ((mode & 2) && !corner_angle)) return HANDS_EINVAL;
+  if (Cpad < 3 + ((mode & 1) ? 4 * n_freq : 0) + ((mode & 2) ? 16 * n_freq : 0)) return HANDS_EINVAL;
+  const long long n = (long long)B * H * W * (Cpad / 4);
+  hipLaunchKernelGGL(image_posenc_kernel, dim3(hands_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, img_nchw,
+                     center_angle, corner_angle, (float4*)out, B, H * W, n_freq, mode, Cpad / 4);
   HANDS_LAUNCH_CHECK();
 }
 

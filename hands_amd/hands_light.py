@@ -16,9 +16,11 @@ statement of ``forward`` runs as a hand-written gfx950 kernel from ``libhands_hi
     :378-390      MANOHead x2                 hands_mano_pose_f32, blend GEMM, hands_mano_skin_f32
     :401-404      grasp classifier            hands_grasp_input_f32, hands_conv2d_nhwc_f32 x4
 
-torch is used for parameter containers, device buffers and streams only.  The default shipped
-configuration is supported (resnet50, pos_enc='center+corner_latent', use_glb_feat, shared hand
-backbone, tf_decoder=False, grasp head on); other switches raise ``NotImplementedError``.
+torch is used for parameter containers, device buffers and streams only.  Built configurations: resnet50,
+shared hand backbone, use_glb_feat, tf_decoder=False with pos_enc in {'center+corner_latent' (shipped default),
+'sinusoidal_cc', 'center', 'corner', 'center+corner', None}, ``no_crops`` (arctic_light), the grasp head with / without
+the global feature vector or absent; the remaining switches (separate_hands, tf_decoder, dense / pcl encodings, depth
+and renderer heads) raise ``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -63,9 +65,9 @@ class _Bottleneck(nn.Module):
 class ResNet50Params(nn.Module):
     """resnet.py:157-280 parameter layout of the ResNet-50 trunk (no avgpool/fc)."""
 
-    def __init__(self):
+    def __init__(self, in_ch=3):
         super().__init__()
-        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.conv1 = nn.Conv2d(in_ch, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         inplanes = 64
         for li, (planes, n) in enumerate(zip((64, 128, 256, 512), RESNET50_LAYERS), start=1):
@@ -237,6 +239,9 @@ class _Args(dict):
         return self.get(k)
 
 
+LATENT_ENC = ("center+corner_latent", "sinusoidal_cc")
+IMAGE_ENC = {"center": 1, "corner": 2, "center+corner": 3}     # -> mode of hands_image_posenc_nhwc_f32
+
 DEFAULT_ARGS = _Args(backbone="resnet50", pos_enc="center+corner_latent", n_freq_pos_enc=4,
                      use_glb_feat=True, separate_hands=False, tf_decoder=False, use_grasp_loss=True,
                      use_glb_feat_w_grasp=True, no_crops=False, use_depth_loss=False,
@@ -270,17 +275,26 @@ class HandsLight(EngineSwitches, nn.Module):
         self.args = args
         if backbone != "resnet50":
             raise NotImplementedError("hands_amd.HandsLight: only backbone='resnet50' is built")
+        # Configuration switches (model.py:33-157).  Built: the latent KPE ('center+corner_latent', and 'sinusoidal_cc' whose
+        # forward is the same code, model.py:258-271 / 288-304), the image-level encodings 'center' / 'corner' /
+        # 'center+corner' (extra input channels of the hand trunk's conv1, model.py:60-77, 203-218), no encoding (None),
+        # `no_crops` (both heads read the pooled global features, model.py:199-201, 316-318: the arctic_light configuration),
+        # the grasp head with and without the global feature vector, or absent.
+        pos_enc = get("pos_enc")
+        self.pos_enc = pos_enc
+        self.enc_mode = ("latent" if pos_enc in LATENT_ENC else "image" if pos_enc in IMAGE_ENC else
+                         "none" if pos_enc is None else None)
+        self.no_crops = bool(get("no_crops", False))
+        self.use_grasp_loss = bool(get("use_grasp_loss", False))
+        self.use_glb_feat_w_grasp = bool(get("use_glb_feat_w_grasp", False))
         unsupported = {
-            "pos_enc": get("pos_enc") != "center+corner_latent",
+            f"pos_enc={pos_enc!r}": self.enc_mode is None,     # 'pcl', 'perspective_correction', 'dense', 'dense_latent', 'cam_conv'
             "separate_hands": bool(get("separate_hands", False)),
             "tf_decoder": bool(get("tf_decoder", False)),
-            "no_crops": bool(get("no_crops", False)),
             "use_depth_loss": bool(get("use_depth_loss", False)),
             "regress_center_corner": bool(get("regress_center_corner", False)),
             "use_render_seg_loss": bool(get("use_render_seg_loss", False)),
             "use_glb_feat=False": not get("use_glb_feat", False),
-            "use_grasp_loss=False": not get("use_grasp_loss", False),
-            "use_glb_feat_w_grasp=False": not get("use_glb_feat_w_grasp", False),
         }
         bad = [k for k, v in unsupported.items() if v]
         if bad:
@@ -289,10 +303,12 @@ class HandsLight(EngineSwitches, nn.Module):
         feat_dim = 2048
         self.feat_dim = feat_dim
         self.backbone = ResNet50Params()
-        self.hand_backbone = ResNet50Params()
+        # model.py:60-77: conv1 of the hand trunk takes the image-level encoding as extra input channels
+        self.enc_channels = {1: 4, 2: 16, 3: 20}[IMAGE_ENC[pos_enc]] * self.n_freq if self.enc_mode == "image" else 0
+        self.hand_backbone = ResNet50Params(3 + self.enc_channels)
         self.head_r = HandHMR(feat_dim, True, 3)
         self.head_l = HandHMR(feat_dim, False, 3)
-        fc_dim = feat_dim + 5 * 4 * self.n_freq
+        fc_dim = feat_dim + (5 * 4 * self.n_freq if self.enc_mode == "latent" else 0)       # model.py:79-88
         self.feature_conv = nn.Sequential(
             nn.Conv2d(fc_dim, 1024, 1, bias=False), nn.ReLU(inplace=True),
             nn.Conv2d(1024, 512, 3, bias=False), nn.ReLU(inplace=True),
@@ -301,9 +317,11 @@ class HandsLight(EngineSwitches, nn.Module):
         assets = mano_assets or (None, None)
         self.mano_r = MANOHead(True, focal_length, img_res, assets[0])
         self.mano_l = MANOHead(False, focal_length, img_res, assets[1])
-        self.grasp_classifier = nn.Sequential(
-            nn.Linear(10 + 144 + feat_dim, 1024), nn.ReLU(inplace=True), nn.Linear(1024, 512),
-            nn.ReLU(inplace=True), nn.Linear(512, 128), nn.ReLU(inplace=True), nn.Linear(128, 9))
+        if self.use_grasp_loss:                                                            # model.py:113-125
+            gdim = 10 + 144 + (feat_dim if self.use_glb_feat_w_grasp else 0)
+            self.grasp_classifier = nn.Sequential(
+                nn.Linear(gdim, 1024), nn.ReLU(inplace=True), nn.Linear(1024, 512),
+                nn.ReLU(inplace=True), nn.Linear(512, 128), nn.ReLU(inplace=True), nn.Linear(128, 9))
         self.mode = "train"
         self.img_res = img_res
         self.focal_length = focal_length
@@ -334,11 +352,16 @@ class HandsLight(EngineSwitches, nn.Module):
         bnp = lambda bn: (cpu(bn.weight), cpu(bn.bias), cpu(bn.running_mean), cpu(bn.running_var))
         P = {}
         w, b = fold_bn(cpu(net.conv1.weight), *bnp(net.bn1))
-        P["stem"] = pack_conv(w, b, 2, 3, dev, cin_pad_to=4)
-        # planar form for hands_stem_conv_maxpool_nchw_f32: k = plane * 52 + tap (49 taps + 3 zero columns per plane)
-        col = [c * 52 + t for c in range(3) for t in range(49)]
-        P["stem_planar"] = pack_linear(w.reshape(64, 147), b, dev, col_index=col, k_total=160)
-        P["stem_planar"].macs_per_pixel = 64 * 147
+        if w.shape[1] == 3:
+            P["stem"] = pack_conv(w, b, 2, 3, dev, cin_pad_to=4)
+            # planar form for hands_stem_conv_maxpool_nchw_f32: k = plane * 52 + tap (49 taps + 3 zero columns per plane)
+            col = [c * 52 + t for c in range(3) for t in range(49)]
+            P["stem_planar"] = pack_linear(w.reshape(64, 147), b, dev, col_index=col, k_total=160)
+            P["stem_planar"].macs_per_pixel = 64 * 147
+        else:
+            # widened conv1 (image-level encodings): the general implicit-GEMM route on an NHWC input whose channel count is
+            # padded to a multiple of 16 (hands_image_posenc_nhwc_f32 writes the zeros)
+            P["stem_wide"] = pack_conv(w, b, 2, 3, dev, cin_pad_to=(w.shape[1] + 15) // 16 * 16)
         blocks = []
         for li in range(1, 5):
             for blk in getattr(net, f"layer{li}"):
@@ -391,13 +414,15 @@ class HandsLight(EngineSwitches, nn.Module):
         # nn.Flatten on NCHW (B,256,3,3): reference column c*9 + hw; NHWC buffer column hw*256 + c
         col = [(k % 9) * 256 + (k // 9) for k in range(256 * 9)]
         P["fc7"] = pack_linear(cpu(fc[7].weight), cpu(fc[7].bias), dev, col_index=col)
-        g = self.grasp_classifier
-        # reference cat([shape 10, rot 144, feat_vec F]) -> packed row [feat_vec F | rot 144 | shape 10]
-        gcol = [F + 144 + i for i in range(10)] + [F + i for i in range(144)] + list(range(F))
-        P["g0"] = pack_linear(cpu(g[0].weight), cpu(g[0].bias), dev, col_index=gcol, k_total=F + 154)
-        P["g2"] = pack_linear(cpu(g[2].weight), cpu(g[2].bias), dev)
-        P["g4"] = pack_linear(cpu(g[4].weight), cpu(g[4].bias), dev)
-        P["g6"] = pack_linear(cpu(g[6].weight), cpu(g[6].bias), dev, n_total=12)
+        if self.use_grasp_loss:
+            g = self.grasp_classifier
+            Fg = F if self.use_glb_feat_w_grasp else 0
+            # reference cat([shape 10, rot 144(, feat_vec F)]) -> packed row [feat_vec F | rot 144 | shape 10]
+            gcol = [Fg + 144 + i for i in range(10)] + [Fg + i for i in range(144)] + list(range(Fg))
+            P["g0"] = pack_linear(cpu(g[0].weight), cpu(g[0].bias), dev, col_index=gcol, k_total=Fg + 154)
+            P["g2"] = pack_linear(cpu(g[2].weight), cpu(g[2].bias), dev)
+            P["g4"] = pack_linear(cpu(g[4].weight), cpu(g[4].bias), dev)
+            P["g6"] = pack_linear(cpu(g[6].weight), cpu(g[6].bias), dev, n_total=12)
         P["mano_r"] = pack_mano(self.mano_r.mano.asset(), dev)
         P["mano_l"] = pack_mano(self.mano_l.mano.asset(), dev)
         for side in ("mano_r", "mano_l"):
@@ -487,7 +512,13 @@ class HandsLight(EngineSwitches, nn.Module):
         img_floats = 3 * res_in * res_in
         done = 0
         for src, first, n in segs:
-            if self.engine.fuse_stem_pool:
+            if "stem_wide" in P:
+                # widened conv1 (image-level encodings): `src` is the NHWC (.., res, res, Cpad) tensor hands_image_posenc_nhwc_f32
+                # wrote; general implicit GEMM + the max-pool kernel
+                Cp = P["stem_wide"].Cin
+                self.engine.conv(L, P["stem_wide"], src, n, res_in, res_in, a, True, stream, x_off=first * res_in * res_in * Cp)
+                check(L.hands_maxpool3x3s2_nhwc_f32(ptr(a), ptr(b, done * Hp * Wp * 64), n, Hs, Ws, 64, stream), "maxpool")
+            elif self.engine.fuse_stem_pool:
                 # conv1 + bn1 + relu + maxpool in one kernel straight from the NCHW image: neither the NHWC copy
                 # of the input nor the 112x112x64 map ever reaches HBM
                 self.engine.stem_pool_nchw(L, P["stem_planar"], src, first * img_floats, b, done * Hp * Wp * 64, n,
@@ -545,9 +576,23 @@ class HandsLight(EngineSwitches, nn.Module):
                 if prev_tail is not None:
                     main.wait_event(prev_tail)
         featg = buf(f"feat_g{par}", bz * 49 * F)
-        feath = buf(f"feat_h{par}", B2 * 49 * F)
+        feath = buf(f"feat_h{par}", B2 * 49 * F) if not self.no_crops else None
         gch, hch = self.trunk_chunks if self.engine.overlap else (1, 1)
-        gch, hch = max(1, min(gch, bz)), max(1, min(hch, B2))
+        if self.no_crops:          # model.py:199-201: no hand trunks; the global job may as well be cut in two
+            gch, hch = (2 if self.engine.overlap else 1), 0
+        gch, hch = max(1, min(gch, bz)), min(hch, B2)
+        center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0) if self.enc_mode != "none" else None
+        corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0) if self.enc_mode != "none" else None
+        wide = None
+        if self.enc_mode == "image" and not self.no_crops:
+            # model.py:203-218: cat([crop, enc repeated over the pixels]) as the NHWC input of the widened conv1
+            Cp = P["hand_backbone"]["stem_wide"].Cin
+            wide = buf("wide_in", B2 * res * res * Cp)
+            mode = IMAGE_ENC[self.pos_enc]
+            for side, im in enumerate((r_img, l_img)):
+                check(L.hands_image_posenc_nhwc_f32(ptr(im), ptr(center, side * bz * 2), ptr(corner, side * bz * 8),
+                                                    ptr(wide, side * bz * res * res * Cp), bz, res, res, self.n_freq, mode, Cp,
+                                                    stream), "image_posenc")
         jobs = []   # (weights, NCHW segments [(tensor, first image, n)], first row of the job, n images, out buffer)
         for c in range(gch):
             lo, hi = c * bz // gch, (c + 1) * bz // gch
@@ -555,10 +600,13 @@ class HandsLight(EngineSwitches, nn.Module):
         for c in range(hch):       # rows [0, bz) of the hand batch are the right crops, [bz, 2 bz) the left crops
             lo, hi = c * B2 // hch, (c + 1) * B2 // hch
             segs = []
-            if lo < bz:
-                segs.append((r_img, lo, min(hi, bz) - lo))
-            if hi > bz:
-                segs.append((l_img, max(lo, bz) - bz, hi - max(lo, bz)))
+            if wide is not None:
+                segs.append((wide, lo, hi - lo))
+            else:
+                if lo < bz:
+                    segs.append((r_img, lo, min(hi, bz) - lo))
+                if hi > bz:
+                    segs.append((l_img, max(lo, bz) - bz, hi - max(lo, bz)))
             jobs.append((P["hand_backbone"], segs, lo, hi - lo, feath))
         ev0 = torch.cuda.Event()
         ev0.record(main)
@@ -578,9 +626,7 @@ class HandsLight(EngineSwitches, nn.Module):
             main.wait_event(ev)
         assert fh * fw == 49
         HW = fh * fw
-        # small per-sample inputs the tail reads: private copies made on the caller's stream
-        center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
-        corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0)
+        # small per-sample inputs the tail reads: private copies made on the caller's stream (center / corner above)
         flipped = meta_info["is_flipped"].to(device=dev, dtype=torch.int64).contiguous()
         if async_tail:
             K, flipped = K.clone(), flipped.clone()
@@ -589,7 +635,8 @@ class HandsLight(EngineSwitches, nn.Module):
             evt.record(main)
             tail.wait_event(evt)
             for t in (center, corner, K, flipped):
-                t.record_stream(tail)
+                if t is not None:
+                    t.record_stream(tail)
         else:
             tail = main
         with torch.cuda.stream(tail):
@@ -607,26 +654,34 @@ class HandsLight(EngineSwitches, nn.Module):
         stream = main.cuda_stream
         buf = lambda n, numel: self._buf(n, numel, dev)
         feat_vec = buf("feat_vec", bz * F)
-        # sum-pool (model.py:196)
-        check(L.hands_sumpool_nhwc_f32(ptr(featg), ptr(feat_vec), bz, HW, F, F, stream), "sumpool")
-
-        # -- KPE concat (model.py:258-271) ----------------------------------------------------------
-        Cc = F + 20 * self.n_freq
-        cat = buf("cat", B2 * HW * Cc)
-        check(L.hands_kpe_concat_f32(ptr(feath), ptr(featg), ptr(center), ptr(corner), ptr(cat), B2, bz,
-                                     HW, F, self.n_freq, stream), "kpe_concat")
-
-        # -- feature_conv (model.py:91-101, 313-314) -> HMR state rows ---------------------------
-        f1 = buf("fc1", B2 * HW * 1024)
-        self.engine.conv(L, P["fc0"], cat, B2, fh, fw, f1, True, stream)
-        f2 = buf("fc2", B2 * (fh - 2) * (fw - 2) * 512)
-        h2, w2 = self.engine.conv(L, P["fc2"], f1, B2, fh, fw, f2, True, stream)
-        f3 = buf("fc3", B2 * (h2 - 2) * (w2 - 2) * 256)
-        h3, w3 = self.engine.conv(L, P["fc4"], f2, B2, h2, w2, f3, True, stream, splitk_n=8)   # 3x3 output map: 72 tiles at bz=256, K=4608
-        assert h3 * w3 * 256 == P["fc7"].Cin
+        if self.use_grasp_loss and self.use_glb_feat_w_grasp:
+            # sum-pool (model.py:196); only the grasp head reads it
+            check(L.hands_sumpool_nhwc_f32(ptr(featg), ptr(feat_vec), bz, HW, F, F, stream), "sumpool")
         ld = F + HMR_VEC
         state = buf("state", B2 * ld)
-        self.engine.conv(L, P["fc7"], f3, B2, 1, 1, state, True, stream, out_ps=ld, splitk=True)
+        if self.no_crops:
+            # model.py:316-318 -> HandHMR.forward(features, use_pool=True) (hand_hmr.py:73-78): both heads read the average-pooled
+            # GLOBAL feature map -- written straight into the feat segment of the right and the left state rows
+            for side in (0, 1):
+                check(L.hands_avgpool_nhwc_f32(ptr(featg), ptr(state, side * bz * ld), bz, HW, F, ld, stream), "avgpool")
+        else:
+            if self.enc_mode == "latent":
+                # -- KPE concat (model.py:258-271, 288-304) ------------------------------------------------
+                Cc = F + 20 * self.n_freq
+                cat = buf("cat", B2 * HW * Cc)
+                check(L.hands_kpe_concat_f32(ptr(feath), ptr(featg), ptr(center), ptr(corner), ptr(cat), B2, bz,
+                                             HW, F, self.n_freq, stream), "kpe_concat")
+            else:
+                cat = feath            # pos_enc None / image-level: feature_conv reads the crop features as they are
+            # -- feature_conv (model.py:91-101, 313-314) -> HMR state rows ---------------------------
+            f1 = buf("fc1", B2 * HW * 1024)
+            self.engine.conv(L, P["fc0"], cat, B2, fh, fw, f1, True, stream)
+            f2 = buf("fc2", B2 * (fh - 2) * (fw - 2) * 512)
+            h2, w2 = self.engine.conv(L, P["fc2"], f1, B2, fh, fw, f2, True, stream)
+            f3 = buf("fc3", B2 * (h2 - 2) * (w2 - 2) * 256)
+            h3, w3 = self.engine.conv(L, P["fc4"], f2, B2, h2, w2, f3, True, stream, splitk_n=8)   # 3x3 output map: 72 tiles at bz=256, K=4608
+            assert h3 * w3 * 256 == P["fc7"].Cin
+            self.engine.conv(L, P["fc7"], f3, B2, 1, 1, state, True, stream, out_ps=ld, splitk=True)
 
         # -- HandHMR x2 (hand_hmr.py:73-92, hmr_layer.py:67-86) ----------------------------------
         caminit4 = buf("caminit4", B2 * 4)
@@ -679,10 +734,13 @@ class HandsLight(EngineSwitches, nn.Module):
                                 float(self.img_res), bz, stream, buf, self.engine)
 
         # -- grasp classifier on the UN-flipped HMR outputs (model.py:401-411) -------------------
+        if not self.use_grasp_loss:
+            return output
+        Fg = F if self.use_glb_feat_w_grasp else 0
         gld = P["g0"].Cin
         gin = buf("grasp_in", B2 * gld)
         check(L.hands_grasp_input_f32(ptr(state, F + 96), ld, ptr(rotmat), ptr(feat_vec), ptr(gin), B2, bz,
-                                      F, gld, stream), "grasp_input")
+                                      Fg, gld, stream), "grasp_input")
         g1, g2, g3 = buf("g1", B2 * 1024), buf("g2", B2 * 512), buf("g3", B2 * 128)
         g4 = torch.empty(B2, 12, device=dev)
         self.engine.conv(L, P["g0"], gin, B2, 1, 1, g1, True, stream, splitk=True)

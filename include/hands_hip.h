@@ -186,6 +186,21 @@ int hands_maxpool3x3s2_nhwc_f32(const float* in, float* out, int B, int H, int W
 int hands_sumpool_nhwc_f32(const float* feat, float* out, int B, int HW, int C, int out_stride,
                            hands_stream_t stream);
 
+/* out[b, c] = mean_p feat[b, p, c]: nn.AdaptiveAvgPool2d(1) at the top of HandHMR.forward(use_pool=True)
+ * (src/nets/hand_heads/hand_hmr.py:73-78), taken when HandsLight runs with no_crops (src/models/hands_light/model.py:316-318,
+ * the arctic_light configuration): both heads read the pooled GLOBAL feature map.  Same summation order as
+ * hands_sumpool_nhwc_f32, then one division by HW. */
+int hands_avgpool_nhwc_f32(const float* feat, float* out, int B, int HW, int C, int out_stride,
+                           hands_stream_t stream);
+
+/* Image-level positional encodings, pos_enc = 'center' (mode 1) | 'corner' (mode 2) | 'center+corner' (mode 3)
+ * (src/models/hands_light/model.py:203-218: torch.cat([img, enc.view(bz,-1,1,1).repeat(1,1,w,h)], dim=1)):
+ * out (B, H, W, Cpad) NHWC = [r g b | center enc 4 n_freq | corner enc 16 n_freq | zero padding], img_nchw (B,3,H,W),
+ * center_angle (B,2), corner_angle (B,8); the encoding is that of hands_kpe_concat_f32 (model.py:444-460).  The result
+ * is the input of the hand trunk's widened conv1 through hands_conv2d_nhwc_f32 (Cin = Cpad, a multiple of 16). */
+int hands_image_posenc_nhwc_f32(const float* img_nchw, const float* center_angle, const float* corner_angle, float* out,
+                                int B, int H, int W, int n_freq, int mode, int Cpad, hands_stream_t stream);
+
 /* out[b2, p, :] = cat(crop[b2,p,:] + glb[b2 % Bg, p, :], center_enc(b2), corner_enc(b2)).
  * crop holds the right-hand samples then the left-hand samples (2*Bg rows); encodings are the
  * reference's [sin(2^k a), cos(2^k a)] laid out (L, c, 2).  model.py:258-271, 444-460.

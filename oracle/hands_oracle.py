@@ -206,7 +206,8 @@ def hand_hmr(feat, sd, p, n_iter=3):
 # ------------------------------------------------------------------------------------------------
 def grasp_classifier(shape, rotmat, feat_vec, sd, p="grasp_classifier"):
     bz = shape.shape[0]
-    x = torch.cat([shape, rotmat.reshape(bz, -1), feat_vec], dim=1)
+    parts = [shape, rotmat.reshape(bz, -1)] + ([feat_vec] if feat_vec is not None else [])     # model.py:402-407
+    x = torch.cat(parts, dim=1)
     for i in (0, 2, 4):
         x = F.relu(F.linear(x, sd[f"{p}.{i}.weight"], sd[f"{p}.{i}.bias"]))
     return F.linear(x, sd[f"{p}.6.weight"], sd[f"{p}.6.bias"])
@@ -319,18 +320,47 @@ def mano_head(rotmat, shape, cam, K, asset, img_res, postfix):
 # HandsLight.forward, default config (src/models/hands_light/model.py:187-437)
 # ------------------------------------------------------------------------------------------------
 @torch.no_grad()
+def image_level_input(img, center_angle, corner_angle, mode, n_freq=4):
+    """model.py:203-218: pos_enc 'center' / 'corner' / 'center+corner' -- the encoding repeated over the pixels as extra
+    input channels of the hand trunk's (widened) conv1."""
+    bz, _, w, h = img.shape
+    parts = [img]
+    if mode in ("center", "center+corner"):
+        parts.append(pos_enc(center_angle, n_freq).view(bz, -1, 1, 1).repeat(1, 1, w, h))
+    if mode in ("corner", "center+corner"):
+        parts.append(pos_enc(corner_angle, n_freq).view(bz, -1, 1, 1).repeat(1, 1, w, h))
+    return torch.cat(parts, dim=1)
+
+
 def hands_light_forward(sd, asset_r, asset_l, inputs, meta_info, img_res=224, n_freq=4,
-                        return_intermediates=False):
+                        return_intermediates=False, pos_enc_mode="center+corner_latent", no_crops=False,
+                        use_grasp_loss=True, use_glb_feat_w_grasp=True):
+    """model.py:187-437 with use_glb_feat=True, shared hand backbone, tf_decoder=False.  ``pos_enc_mode``:
+    'center+corner_latent' | 'sinusoidal_cc' (same code path, model.py:258-271 / 288-304), 'center' | 'corner' |
+    'center+corner' (image level, model.py:203-218) or None."""
     K = meta_info["intrinsics"]
     bz = inputs["img"].shape[0]
     features = resnet50_trunk(inputs["img"], sd, "backbone")                      # model.py:193
     feat_vec = features.view(bz, features.shape[1], -1).sum(dim=2)                # model.py:196 (SUM)
-    r_feat = resnet50_trunk(inputs["r_img"], sd, "hand_backbone")                 # model.py:238
-    l_feat = resnet50_trunk(inputs["l_img"], sd, "hand_backbone")                 # model.py:239
-    r_cat = assemble_features(r_feat, features, inputs["r_center_angle"], inputs["r_corner_angle"], n_freq)
-    l_cat = assemble_features(l_feat, features, inputs["l_center_angle"], inputs["l_corner_angle"], n_freq)
-    r_vec = feature_conv(r_cat, sd)                                               # model.py:313
-    l_vec = feature_conv(l_cat, sd)                                               # model.py:314
+    r_feat = l_feat = None
+    if no_crops:                                                                  # model.py:199-201, 316-318
+        # HandHMR.forward(features, use_pool=True): nn.AdaptiveAvgPool2d(1) (hand_hmr.py:73-78)
+        r_vec = l_vec = F.adaptive_avg_pool2d(features, 1).view(bz, -1)
+    else:
+        if pos_enc_mode in ("center", "corner", "center+corner"):
+            r_in = image_level_input(inputs["r_img"], inputs["r_center_angle"], inputs["r_corner_angle"], pos_enc_mode, n_freq)
+            l_in = image_level_input(inputs["l_img"], inputs["l_center_angle"], inputs["l_corner_angle"], pos_enc_mode, n_freq)
+        else:
+            r_in, l_in = inputs["r_img"], inputs["l_img"]
+        r_feat = resnet50_trunk(r_in, sd, "hand_backbone")                        # model.py:238
+        l_feat = resnet50_trunk(l_in, sd, "hand_backbone")                        # model.py:239
+        if pos_enc_mode in ("center+corner_latent", "sinusoidal_cc"):
+            r_cat = assemble_features(r_feat, features, inputs["r_center_angle"], inputs["r_corner_angle"], n_freq)
+            l_cat = assemble_features(l_feat, features, inputs["l_center_angle"], inputs["l_corner_angle"], n_freq)
+        else:
+            r_cat, l_cat = r_feat, l_feat            # the global features are NOT added on these routes (model.py:241-304)
+        r_vec = feature_conv(r_cat, sd)                                           # model.py:313
+        l_vec = feature_conv(l_cat, sd)                                           # model.py:314
     hmr_r = hand_hmr(r_vec, sd, "head_r")                                         # model.py:320
     hmr_l = hand_hmr(l_vec, sd, "head_l")                                         # model.py:321
 
@@ -366,9 +396,11 @@ def hands_light_forward(sd, asset_r, asset_l, inputs, meta_info, img_res=224, n_
     ml["cam_t.wp.init.l"] = root_l_init
     out.update({"mano." + k: v for k, v in mr.items()})
     out.update({"mano." + k: v for k, v in ml.items()})
-    # model.py:401-404: the grasp head reads the UN-flipped HMR outputs
-    out["grasp.r"] = grasp_classifier(hmr_r["shape"], hmr_r["pose"], feat_vec, sd)
-    out["grasp.l"] = grasp_classifier(hmr_l["shape"], hmr_l["pose"], feat_vec, sd)
+    # model.py:401-411: the grasp head reads the UN-flipped HMR outputs
+    if use_grasp_loss:
+        gf = feat_vec if use_glb_feat_w_grasp else None
+        out["grasp.r"] = grasp_classifier(hmr_r["shape"], hmr_r["pose"], gf, sd)
+        out["grasp.l"] = grasp_classifier(hmr_l["shape"], hmr_l["pose"], gf, sd)
     if return_intermediates:
         inter = {"features": features, "feat_vec": feat_vec, "r_feat": r_feat, "l_feat": l_feat,
                  "r_vec": r_vec, "l_vec": l_vec, "hmr_r": hmr_r, "hmr_l": hmr_l}

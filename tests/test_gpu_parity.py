@@ -975,3 +975,36 @@ def test_splitk_n_is_deterministic_and_right(case):
     ref = {0: ref, 1: F.relu(ref), 2: F.gelu(ref), 3: F.leaky_relu(ref, 0.01)}[act]
     got = outs[True].permute(0, 3, 1, 2)[:, :Cout].double().cpu()
     assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("name", ["arctic", "sinusoidal_cc", "center", "corner", "center_corner", "plain"])
+def test_switch_configurations_vs_reference_fixtures(golden_dir, name):
+    """Non-default HandsLight switches through the HIP path against what the REFERENCE produced for them
+    (tests/golden/make_golden_switches.py): `no_crops` (arctic_light: hands_avgpool_nhwc_f32 -> both heads), the image-level
+    encodings (hands_image_posenc_nhwc_f32 -> widened conv1 on the general implicit-GEMM route + max-pool), pos_enc None,
+    'sinusoidal_cc', the grasp head without the global feature vector / absent.  Same bar as the default configuration."""
+    from switch_cases import load_case
+    d, cfg, args, inputs, meta_info = load_case(golden_dir, name)
+    model = hands_amd.apply_recipe(hands_amd.HandsLight(args=args)).eval().to(DEV)
+    dev = lambda t: {k: v.to(DEV) for k, v in t.items()}
+    out = model(dev(inputs), dev(meta_info))
+    torch.cuda.synchronize()
+    keys = [k[4:] for k in d.files if k.startswith("out/")]
+    assert sorted(out.keys()) == sorted(keys)
+    for k in keys:
+        ref, got = d["out/" + k], out[k].cpu().numpy()
+        assert got.shape == ref.shape, k
+        if k.startswith("grasp"):
+            np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4, err_msg=k)
+        elif ".cam." in k or k.startswith("mano.cam_t."):
+            np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5, err_msg=k)
+        else:
+            np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5, err_msg=k)
+    for hn in "rl":
+        verr = np.abs(out[f"mano.vertices.{hn}"].cpu().numpy() - d[f"out/mano.vertices.{hn}"]).max()
+        mp = O.mpjpe_ra_mm(out[f"mano.joints3d.{hn}"].cpu(), torch.from_numpy(d[f"out/mano.joints3d.{hn}"]))
+        assert verr < 1e-6 and mp < 1e-3, (name, hn, verr, mp)
+    # batch independence holds on these routes too: sample 1 alone == sample 1 of the pair
+    one = model({k: v[1:].contiguous() for k, v in dev(inputs).items()}, {k: v[1:].contiguous() for k, v in dev(meta_info).items()})
+    for k in keys:
+        assert torch.equal(one[k], out[k][1:]), k

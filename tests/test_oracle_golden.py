@@ -114,3 +114,32 @@ def test_state_dict_keys_match_reference(golden_dir, recipe_model):
     ref = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
     mine = {k: list(v.shape) for k, v in recipe_model.state_dict().items() if ".mano." not in k}
     assert mine == ref and len(ref) == 681
+
+
+@pytest.mark.parametrize("name", ["arctic", "sinusoidal_cc", "center", "corner", "center_corner", "plain"])
+def test_switch_configurations_match_reference(golden_dir, name):
+    """Non-default HandsLight switches (model.py:40-47,60-86,127,199-232,316-318,401-411): the host mirror builds the
+    reference's parameter tree for the configuration (names + shapes from the reference's own state_dict) and the oracle
+    reproduces the reference's outputs on the seeded inputs."""
+    import hands_amd
+    from switch_cases import load_case, oracle_kwargs
+    d, cfg, args, inputs, meta_info = load_case(golden_dir, name)
+    model = hands_amd.apply_recipe(hands_amd.HandsLight(args=args)).eval()
+    base = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
+    diff = json.load(open(os.path.join(golden_dir, "switch_state_dict_keys.json")))[name]
+    want = {k: v for k, v in base.items() if k not in diff["absent"]}
+    want.update(diff["changed"])
+    mine = {k: list(v.shape) for k, v in model.state_dict().items() if ".mano." not in k}
+    assert mine == want and len(mine) == diff["n_keys"]
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    out = O.hands_light_forward(sd, synthetic_mano_asset(True), synthetic_mano_asset(False), inputs, meta_info,
+                                **oracle_kwargs(cfg))
+    keys = sorted(k[4:] for k in d.files if k.startswith("out/"))
+    assert sorted(out.keys()) == keys and len(keys) == (22 if cfg.get("use_grasp_loss", True) else 20)
+    for k in keys:
+        tol = 1e-4 if k.startswith("grasp") else 2e-5
+        np.testing.assert_allclose(out[k].numpy(), d["out/" + k], rtol=tol if (".cam." in k or "cam_t" in k or k.startswith("grasp")) else 0,
+                                   atol=tol, err_msg=k)
+    for hn in "rl":
+        assert np.abs(out[f"mano.vertices.{hn}"].numpy() - d[f"out/mano.vertices.{hn}"]).max() < 1e-6
+        assert O.mpjpe_ra_mm(out[f"mano.joints3d.{hn}"], torch.from_numpy(d[f"out/mano.joints3d.{hn}"])) < 1e-3
