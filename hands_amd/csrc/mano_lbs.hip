@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
   float (*sJ)[NJ][3] = reinterpret_cast<float (*)[NJ][3]>(sScratch);
   float (*sG)[NJ][12] = reinterpret_cast<float (*)[NJ][12]>(sScratch + MH * NJ * 3);
   float (*stage)[VROW] = reinterpret_cast<float (*)[VROW]>(sScratch);
-  __shared__ float sA[MH][NJ * 12];
+  __shared__ __attribute__((aligned(16))) float sAT[MH][4][12][4];
   __shared__ __attribute__((aligned(16))) float sBin[MH][BROW];
   __shared__ float sCam[MH][3];
   __shared__ float sTip[MH][5][3];
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
   // ---- phase 1: pose, joints, forward kinematics: thread = (hand h or h + 16, joint j) ----------------------
 #if defined(HANDS_MANO_ABL) && HANDS_MANO_ABL == 1      // timing-only ablation (tools/build_variant.sh): no pose / FK
   for (int e = tid; e < MH * BROW; e += 256) (&sBin[0][0])[e] = 0.f;
-  for (int e = tid; e < MH * NJ * 12; e += 256) (&sA[0][0])[e] = 0.f;
+  for (int e = tid; e < MH * NJ * 12; e += 256) (&sAT[0][0][0][0])[e] = 0.f;
   if (tid < MH * 3) (&sCam[0][0])[tid] = 0.f;
   __syncthreads();
 #else
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
       const int b = b0 + h;
       if (b < B) {
         const float* g = sG[h][j];
-        float* am = sA[h] + j * 12;
+        float am[12];
         const float j0 = sJ[h][j][0], j1 = sJ[h][j][1], j2 = sJ[h][j][2];
         const float cx = sCam[h][0], cy = sCam[h][1], cz = sCam[h][2];
         float p[3];
@@ -356,6 +356,11 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
           am[rr * 4 + 0] = g[rr * 4 + 0]; am[rr * 4 + 1] = g[rr * 4 + 1]; am[rr * 4 + 2] = g[rr * 4 + 2];
           am[rr * 4 + 3] = g[rr * 4 + 3] - (g[rr * 4 + 0] * j0 + g[rr * 4 + 1] * j1 + g[rr * 4 + 2] * j2);
           p[rr] = g[rr * 4 + 3];
+        }
+        {
+          float (*at)[12][4] = sAT[h];
+#pragma unroll
+          for (int e = 0; e < 12; ++e) at[j & 3][e][j >> 2] = am[e];
         }
         if (blockIdx.z == 0) {       // the 16 posed joints + camera outputs: written by the first vertex-range block
           float* dj3 = S.o.joints3d + ((long long)b * 21 + j) * 3;
@@ -414,6 +419,7 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
     }
 #pragma unroll
     for (int tt = 0; tt < 3; ++tt) {
+      if (tt > 0 && ch == NCHUNK - 1) break;           // chunk 12 holds vertices in its first two row tiles only (2304 ... 2335)
       int m0 = ch * CHUNK_M + (wave + 4 * tt) * 16;
       m0 = m0 < 2432 ? m0 : 2432 - 16;
       const float4 bias = *reinterpret_cast<const float4*>(S.blend_bias + m0 + 4 * g);
@@ -432,6 +438,7 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
       for (int s4 = 0; s4 < 10; ++s4) {
 #pragma unroll
         for (int nt = 0; nt < MH / 16; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s4].x, bfrag[nt][s4].x, acc[nt], 0, 0, 0);
+        if (s4 == 9) continue;       // .y .z .w of the last step are k = 145 ... 159: the zero padding of the input row
 #pragma unroll
         for (int nt = 0; nt < MH / 16; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s4].y, bfrag[nt][s4].y, acc[nt], 0, 0, 0);
 #pragma unroll
@@ -467,9 +474,8 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
       float av[4][4];
 #pragma unroll
       for (int hh = 0; hh < 4; ++hh) {
-        const float* am = sA[h0 + hh];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) av[hh][s4] = e12 < 12 ? am[(4 * s4 + g) * 12 + e12] : 0.f;
+        const float4 a4 = e12 < 12 ? *reinterpret_cast<const float4*>(sAT[h0 + hh][g][e12]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        av[hh][0] = a4.x; av[hh][1] = a4.y; av[hh][2] = a4.z; av[hh][3] = a4.w;
         T[hh][0] = 0.f; T[hh][1] = 0.f; T[hh][2] = 0.f; T[hh][3] = 0.f;
       }
 #pragma unroll
