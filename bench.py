@@ -190,7 +190,7 @@ def pmc_traffic_per_launch(workload, bz):
     """(GB per conv_igemm launch, source file) from the newest committed rocprofv3 --pmc summary TAKEN AT THIS BATCH SIZE,
     or (None, None): a per-launch traffic figure of another batch size must never be divided by this run's algorithmic
     bytes (round 2 printed 8.68x for handoccnet_light that way)."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         for fn in (os.path.join(ROOT, "profiles", f"{rnd}_pmc_{workload}_bz{bz}.json"),
                    os.path.join(ROOT, "profiles", f"{rnd}_pmc_{workload}.json")):
             try:

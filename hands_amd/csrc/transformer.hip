@@ -4,12 +4,14 @@
 // Reference: src/models/hamer_light/{model.py:75-151, vit.py:89-151,320-342, pos_emb.py:28-64,
 // pose_transformer.py:89-124,160-201}.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include "hands_hip.h"
 #include "common.h"
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // exp(x) for finite x <= 0: exp2 of a compensated x * log2(e) (v_exp_f32 on [-0.5, 0.5] + v_ldexp_f32, ~1 ulp; the
@@ -142,33 +144,51 @@ __global__ void kpe_encode_kernel(const float* __restrict__ center, const float*
 }
 
 // ---- multi-head self-attention on fp32 MFMA -----------------------------------------------------------
-// One block per (head, batch); TB waves, each owns 32 query tokens and ALL T = 32*TB keys.
+// One workgroup per (head, crop): T = 16 * TW tokens, TW waves of 16 queries each, on v_mfma_f32_16x16x4_f32.
 //   S^T[key][query] = sum_d K[key][d] * (scale * Q[query][d])      (K rows = MFMA A, Q rows = MFMA B)
-// so a lane holds, for ITS query (lane&31), 16 keys per 32-key block: softmax over keys is lane-local
-// plus one exchange with lane^32.  The probabilities then feed the second GEMM directly from registers:
+// A lane holds, for ITS query (lane & 15), four keys of every 16-key block (keys 16 kb + 4 g + i, g = lane >> 4): the
+// softmax over keys is lane-local plus two exchanges (lane ^ 16, lane ^ 32).  The probabilities feed the second product
+// straight from the accumulator registers:
 //   O^T[d][query] = sum_key V^T[d][key] * P[key][query]           (V^T rows = MFMA A, P = MFMA B)
-// where MFMA step r of key block kb contracts the key pair {(r&3)+8(r>>2), +4} -- exactly the keys the
-// two half-waves hold in accumulator register r.  K and V^T are staged in LDS one after the other.
-template <int TB, int D>
-__global__ void __launch_bounds__(64 * TB) __attribute__((amdgpu_waves_per_eu(3, 3))) attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                            int heads, float scale) {
-  constexpr int T = 32 * TB;
-  constexpr int KR = D + 4;          // K row (floats): (D+4)*4 B is an odd number of 16-B slots for D = 80
-  constexpr int DB = (D + 31) / 32;  // 32-row blocks of V^T
+// where MFMA step i of key block kb contracts the keys {16 kb + 4 g + i : g = 0..3} -- exactly the keys the four lane
+// groups hold in accumulator register i.
+//
+// Why 12 waves of 16 queries and not 6 waves of 32 (the form of rounds 1-3, on v_mfma_f32_32x32x2_f32): tools/prof_attn.py
+// (per-wave phase stamps + HW_ID) showed that a 6-wave workgroup lands 2-2-1-1 on a CU's four SIMDs -- with two such
+// workgroups resident two SIMDs carry four waves and two carry two, the light SIMDs' waves wait at the workgroup barriers for
+// the loaded ones (p90 25 us of a 60 us wave life) and the matrix pipe sat at 48 % busy.  Twelve waves are three per SIMD;
+// the head dimension 80 is five 16-row blocks exactly (the 32-row form padded it to 96: 17 % of the P.V MFMAs) and the score
+// registers halve (48 per lane): 80 VGPRs and 64.5 KB of LDS (V^T takes K's place) = TWO workgroups per CU, six waves per
+// SIMD, so one workgroup's fill and barrier phases run under the other's MFMAs; V is requested right after the first barrier
+// and waits in registers under Q.K^T.  358 -> 266 us per call at 128 crops (round 4; own LDS regions for K and V^T, one
+// workgroup per CU: 284 us).
+template <int TW, int D>
+constexpr int attention_lds_bytes() {
+  return 4 * (16 * TW * (D + 4) > D * (16 * TW + 4) ? 16 * TW * (D + 4) : D * (16 * TW + 4));     // K, then V^T in its place
+}
+
+template <int TW, int D>
+__global__ void __launch_bounds__(64 * TW) __attribute__((amdgpu_waves_per_eu(6, 6))) attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int heads, float scale) {
+  constexpr int T = 16 * TW;
+  constexpr int KR = D + 4;          // K row (floats): (D + 4) * 4 B = an odd number of 16-byte slots for D = 80
   constexpr int VR = T + 4;          // V^T row
-  constexpr int NT = 64 * TB;
-  static_assert(D % 8 == 0, "head dim must be a multiple of 8");
-  __shared__ __attribute__((aligned(16))) float lds[(T * KR > DB * 32 * VR) ? T * KR : DB * 32 * VR];
+  constexpr int NT = 64 * TW;
+  constexpr int NKK = D / 16;        // 16-float steps of the head dimension: one float4 per lane group and step
+  constexpr int DB = D / 16;         // 16-row blocks of V^T / O^T
+  constexpr int FILL = T * (D / 4) / NT;
+  static_assert(D % 16 == 0 && T * (D / 4) % NT == 0 && NT % T == 0, "fill loops assume whole iterations");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sK = lds;                   // [T][KR]
+  float* sV = lds;                   // [D][VR]  (V transposed) in K's place, once every wave is done with K
 
   const int h = blockIdx.x, b = blockIdx.y;
   const int C = heads * D;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
   const float* base = qkv + (long long)b * T * 3 * C + h * D;
 
-  // K tile -> LDS (coalesced 16-B loads along d)
-  // (all loads of a thread in flight before its first LDS store: T * D / 4 is a multiple of the block size)
-  constexpr int FILL = T * (D / 4) / NT;
-  static_assert(T * (D / 4) % NT == 0, "fill loops assume whole iterations");
+  // K tile -> LDS: consecutive lanes walk the 16-byte slots of a token's row (coalesced 320-byte rows); all loads of a
+  // thread in flight before its first LDS store
   {
     float4 kv[FILL];
 #pragma unroll
@@ -181,111 +201,102 @@ __global__ void __launch_bounds__(64 * TB) __attribute__((amdgpu_waves_per_eu(3,
     for (int it = 0; it < FILL; ++it) {
       const int i = tid + it * NT;
       const int t = i / (D / 4), dq = i - t * (D / 4);
-      *reinterpret_cast<float4*>(lds + t * KR + dq * 4) = kv[it];
+      *reinterpret_cast<float4*>(sK + t * KR + dq * 4) = kv[it];
     }
   }
-  // this wave's Q fragments (pre-scaled: vit.py:118 scales q before the matmul)
-  float4 qf[D / 8];
+  // this wave's Q fragments, pre-scaled (vit.py:118 scales q before the matmul): lane (query l15, group g) holds
+  // d = 16 kk + 4 g + j
+  float4 qf[NKK];
   {
-    const float* qrow = base + (long long)(wave * 32 + (lane & 31)) * 3 * C + half * 4;
+    const float* qrow = base + (long long)(wave * 16 + l15) * 3 * C + 4 * g;
 #pragma unroll
-    for (int kk = 0; kk < D / 8; ++kk) {
-      float4 v = *reinterpret_cast<const float4*>(qrow + kk * 8);
+    for (int kk = 0; kk < NKK; ++kk) {
+      float4 v = *reinterpret_cast<const float4*>(qrow + kk * 16);
       v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
       qf[kk] = v;
     }
   }
   __syncthreads();
+  // V: requested now (after the barrier, whose s_waitcnt would otherwise wait for it), parked in registers under Q.K^T and
+  // transposed into LDS afterwards.  thread = (token ft, 16-byte slot fq + it * NT / T): lanes walk tokens,
+  // so the transposed scalar LDS writes are conflict-free
+  const int ft = tid % T, fq = tid / T;
+  float4 vv[FILL];
+#pragma unroll
+  for (int it = 0; it < FILL; ++it) vv[it] = *reinterpret_cast<const float4*>(base + (long long)ft * 3 * C + 2 * C + (fq + it * (NT / T)) * 4);
 
-  f32x16 s[TB];
+  // S^T = K . (scale Q)^T: TW independent accumulation chains (one per key block), the k-step outermost
+  f32x4 s[TW];
 #pragma unroll
-  for (int kb = 0; kb < TB; ++kb) {
+  for (int kb = 0; kb < TW; ++kb) { s[kb][0] = 0.f; s[kb][1] = 0.f; s[kb][2] = 0.f; s[kb][3] = 0.f; }
+  {
+    const float* krow = sK + l15 * KR + 4 * g;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-    const float* krow = lds + (kb * 32 + (lane & 31)) * KR + half * 4;
+    for (int kk = 0; kk < NKK; ++kk) {
 #pragma unroll
-    for (int kk = 0; kk < D / 8; ++kk) {
-      const float4 kf = *reinterpret_cast<const float4*>(krow + kk * 8);
+      for (int kb = 0; kb < TW; ++kb) {
+        const float4 kf = *reinterpret_cast<const float4*>(krow + kb * 16 * KR + kk * 16);
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(kf, t), f4e(qf[kk], t), s[kb], 0, 0, 0);
+        for (int j = 0; j < 4; ++j)
+          s[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(kf, j), f4e(qf[kk], j), s[kb], 0, 0, 0);
+      }
     }
   }
-  // softmax over the keys of this lane's query: exp(x - max) * (1 / sum): one reciprocal per query instead of 96
-  // divisions (~10 instructions each); e * (1 / sum) vs e / sum differ by the last rounding only
+  __syncthreads();   // every wave is done with K
+  // V^T -> LDS in K's place (lanes walk tokens: the transposed scalar writes are conflict-free)
+#pragma unroll
+  for (int it = 0; it < FILL; ++it) {
+    float* d = sV + (fq + it * (NT / T)) * 4 * VR + ft;
+    d[0 * VR] = vv[it].x;
+    d[1 * VR] = vv[it].y;
+    d[2 * VR] = vv[it].z;
+    d[3 * VR] = vv[it].w;
+  }
+  // softmax over the keys of this lane's query: exp(x - max) * (1 / sum): one reciprocal per query; e * (1 / sum) vs
+  // e / sum differ by the last rounding only
   float m = s[0][0];
 #pragma unroll
-  for (int kb = 0; kb < TB; ++kb)
+  for (int kb = 0; kb < TW; ++kb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kb][r]);
+    for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kb][r]);
+  m = fmaxf(m, __shfl_xor(m, 16));
   m = fmaxf(m, __shfl_xor(m, 32));
   float sum = 0.f;
 #pragma unroll
-  for (int kb = 0; kb < TB; ++kb)
+  for (int kb = 0; kb < TW; ++kb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[kb][r] = exp_nonpos(s[kb][r] - m); sum += s[kb][r]; }
+    for (int r = 0; r < 4; ++r) { s[kb][r] = exp_nonpos(s[kb][r] - m); sum += s[kb][r]; }
+  sum += __shfl_xor(sum, 16);
   sum += __shfl_xor(sum, 32);
   const float inv_sum = 1.0f / sum;
 #pragma unroll
-  for (int kb = 0; kb < TB; ++kb)
+  for (int kb = 0; kb < TW; ++kb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[kb][r] *= inv_sum;
+    for (int r = 0; r < 4; ++r) s[kb][r] *= inv_sum;
+  __syncthreads();   // V^T complete
 
-  __syncthreads();   // every wave is done with K
-  __builtin_amdgcn_sched_barrier(0);      // keep the 10 loads below the softmax: hoisted, they cost the third wave per SIMD
-  // V^T -> LDS: lanes walk tokens, so the transposed scalar writes are conflict-free; all loads of a thread in flight
-  // before its first LDS store
+  // O^T = V^T . P: DB independent chains (one per 16-row block of V^T), the key block outermost
+  f32x4 o[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db) { o[db][0] = 0.f; o[db][1] = 0.f; o[db][2] = 0.f; o[db][3] = 0.f; }
   {
-    float4 vv[FILL];
+    const float* vrow = sV + l15 * VR + 4 * g;
 #pragma unroll
-    for (int it = 0; it < FILL; ++it) {
-      const int i = tid + it * NT;
-      const int t = i % T, dq = i / T;
-      vv[it] = *reinterpret_cast<const float4*>(base + (long long)t * 3 * C + 2 * C + dq * 4);
-    }
+    for (int kb = 0; kb < TW; ++kb) {
 #pragma unroll
-    for (int it = 0; it < FILL; ++it) {
-      const int i = tid + it * NT;
-      const int t = i % T, dq = i / T;
-      lds[(dq * 4 + 0) * VR + t] = vv[it].x;
-      lds[(dq * 4 + 1) * VR + t] = vv[it].y;
-      lds[(dq * 4 + 2) * VR + t] = vv[it].z;
-      lds[(dq * 4 + 3) * VR + t] = vv[it].w;
+      for (int db = 0; db < DB; ++db) {
+        const float4 vf = *reinterpret_cast<const float4*>(vrow + db * 16 * VR + kb * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(vf, i), s[kb][i], o[db], 0, 0, 0);
+      }
     }
   }
-  __syncthreads();
-
-  f32x16 o[DB];
+  // O^T[d = 16 db + 4 g + i][query l15] -> out[(b*T + query)*C + h*D + d], 4 consecutive d per store
+  float* orow = out + ((long long)b * T + wave * 16 + l15) * C + h * D + 4 * g;
 #pragma unroll
   for (int db = 0; db < DB; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-#pragma unroll
-  for (int kb = 0; kb < TB; ++kb) {
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      float4 vf[DB];
-#pragma unroll
-      for (int db = 0; db < DB; ++db)
-        vf[db] = *reinterpret_cast<const float4*>(lds + (db * 32 + (lane & 31)) * VR + kb * 32 + q4 * 8 + half * 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(vf[db], i), s[kb][q4 * 4 + i], o[db], 0, 0, 0);
-    }
-  }
-  // O^T[d][query] -> out[(b*T + query)*C + h*D + d], 4 consecutive d per store
-  float* orow = out + ((long long)b * T + wave * 32 + (lane & 31)) * C + h * D;
-#pragma unroll
-  for (int db = 0; db < DB; ++db)
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      const int d0 = db * 32 + q4 * 8 + half * 4;
-      if (d0 < D)
-        *reinterpret_cast<float4*>(orow + d0) =
-            make_float4(o[db][q4 * 4 + 0], o[db][q4 * 4 + 1], o[db][q4 * 4 + 2], o[db][q4 * 4 + 3]);
-    }
+    *reinterpret_cast<float4*>(orow + db * 16) = make_float4(o[db][0], o[db][1], o[db][2], o[db][3]);
 }
 
 // ---- single-query cross-attention (decoder head): one wave per (batch, head), head dim 64 ------------
@@ -396,11 +407,22 @@ int hands_kpe_encode_f32(const float* center_angle, const float* corner_angle, f
 int hands_attention_f32(const float* qkv, float* out, int B, int T, int heads, int head_dim, float scale,
                         hands_stream_t stream) {
   if (!qkv || !out || B <= 0 || heads <= 0) return HANDS_EINVAL;
-  if (T == 192 && head_dim == 80)
-    hipLaunchKernelGGL((attention_kernel<6, 80>), dim3(heads, B), dim3(384), 0, (hipStream_t)stream, qkv, out,
-                       heads, scale);
-  else
+  if (T == 192 && head_dim == 80) {
+    // 127 KB of dynamic LDS (> the 64 KB default cap of a launch): raise the kernel's limit once per device
+    static std::atomic<int> lds_set[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return HANDS_EINVAL;
+    if (!lds_set[dev].load(std::memory_order_acquire)) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<12, 80>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, attention_lds_bytes<12, 80>());
+      if (e != hipSuccess) return (int)e;
+      lds_set[dev].store(1, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((attention_kernel<12, 80>), dim3(heads, B), dim3(768), (attention_lds_bytes<12, 80>()), (hipStream_t)stream,
+                       qkv, out, heads, scale);
+  } else {
     return HANDS_EINVAL;
+  }
   HANDS_LAUNCH_CHECK();
 }
 

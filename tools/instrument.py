@@ -9,6 +9,7 @@ loudly here instead of silently measuring something else.
                                          workgroup (tools/prof_clock.py)
   python tools/instrument.py ring    -> build_ab/prof_ring.so    conv_igemm: the middle workgroup of every plain launch stamps
                                          both clocks into a ring (tools/prof_ring.py)
+  python tools/instrument.py attn    -> build_ab/prof_attn.so    attention_kernel: seven phase stamps per wave (tools/prof_attn.py)
   python tools/instrument.py stem    -> build_ab/prof_stem.so    stem_pool_planar_kernel: entry / after the patch fill / after
                                          the GEMM / exit (tools/stem_prof.py)
 Then e.g.:  HANDS_HIP_LIB=build_ab/prof_tile.so python tools/prof_tile.py 256,256,32,256,1,1,0,0
@@ -22,6 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONV = os.path.join(ROOT, "hands_amd", "csrc", "conv_igemm.hip")
 STEM = os.path.join(ROOT, "hands_amd", "csrc", "stem_pool.hip")
 WINO = os.path.join(ROOT, "hands_amd", "csrc", "conv_wino.hip")
+TRANS = os.path.join(ROOT, "hands_amd", "csrc", "transformer.hip")
 
 
 def sub(s, old, new, what):
@@ -160,14 +162,41 @@ typedef float f32x16""", "globals")
     s = sub(s, "    ++nbi;\n  }\n", "    ++nbi;\n    __builtin_amdgcn_sched_barrier(0); epi_t += __builtin_amdgcn_s_memtime() - epi_0; "
             "__builtin_amdgcn_sched_barrier(0);\n  }\n  " + st % 5 +
             "\n  if (threadIdx.x == 0 && blockIdx.x < 32768) g_wprof[blockIdx.x * 8 + 4] = epi_t;\n", "exit")
-    # expand phase (fused conv3): slot 6 = its start (after the barrier), slot 7 = its end
-    s = sub(s, "    constexpr int NKK = XCM / 8;\n    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");          // this wave's t2 stores have reached the L2\n    __syncthreads();\n",
-            "    constexpr int NKK = XCM / 8;\n    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    __syncthreads();\n    " + st % 6 + "\n", "expand start")
-    s = sub(s, "#undef WINO_LOADID\n#undef WINO_EXPAND\n", "#undef WINO_LOADID\n#undef WINO_EXPAND\n    " + st % 7 + "\n", "expand end")
     return s, "conv_wino.hip"
 
 
-KINDS = {"wino": (wino_phases, "prof_wino"), "tile": (conv_tile_timeline, "prof_tile"), "clock": (conv_clock, "prof_clock"), "ring": (conv_ring, "prof_ring"),
+def attn_phases():
+    """attention_kernel<12,80> (ViT self-attention, csrc/transformer.hip): s_memrealtime of lane 0 of EVERY wave at entry / after
+    the K fill's barrier / after Q.K^T / after the V^T write / after the softmax / after the barrier / after P.V + stores;
+    slot 7 = HW_ID | XCC_ID << 32 (tools/prof_attn.py)"""
+    s = open(TRANS).read()
+    s = sub(s, "namespace {\n", """__device__ unsigned long long g_aprof[32768 * 8];
+extern "C" int hands_debug_aprof(void* dst) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_aprof), sizeof(unsigned long long) * 32768 * 8);
+  return 0;
+}
+namespace {
+""", "globals")
+    i = s.index("attention_kernel(const float* __restrict__ qkv")
+    head, body = s[:i], s[i:]
+    st = ("__builtin_amdgcn_sched_barrier(0); if ((threadIdx.x & 63) == 0 && pslot < 32768) g_aprof[pslot * 8 + %d] = "
+          "__builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0);")
+    body = sub(body, "  const float* base = qkv + (long long)b * T * 3 * C + h * D;\n",
+               "  const float* base = qkv + (long long)b * T * 3 * C + h * D;\n"
+               "  const int pslot = (blockIdx.y * gridDim.x + blockIdx.x) * TW + (threadIdx.x >> 6);\n  " + st % 0 + "\n", "entry")
+    body = sub(body, "  __syncthreads();\n  // V: requested now", "  __syncthreads();\n  " + st % 1 + "\n  // V: requested now", "K fill")
+    body = sub(body, "  __syncthreads();   // every wave is done with K\n", "  " + st % 2 + "\n  __syncthreads();   // every wave is done with K\n", "QK")
+    body = sub(body, "  // softmax over the keys of this lane's query", "  " + st % 3 + "\n  // softmax over the keys of this lane's query", "V write")
+    body = sub(body, "  __syncthreads();   // V^T complete\n", "  " + st % 4 + "\n  __syncthreads();   // V^T complete\n  " + st % 5 + "\n", "softmax")
+    body = sub(body, "    *reinterpret_cast<float4*>(orow + db * 16) = make_float4(o[db][0], o[db][1], o[db][2], o[db][3]);\n}\n",
+               "    *reinterpret_cast<float4*>(orow + db * 16) = make_float4(o[db][0], o[db][1], o[db][2], o[db][3]);\n  " + st % 6 +
+               "\n  if ((threadIdx.x & 63) == 0 && pslot < 32768) g_aprof[pslot * 8 + 7] = "
+               "(unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);\n}\n", "exit")
+    return head + body, "transformer.hip"
+
+
+KINDS = {"attn": (attn_phases, "prof_attn"), "wino": (wino_phases, "prof_wino"), "tile": (conv_tile_timeline, "prof_tile"), "clock": (conv_clock, "prof_clock"), "ring": (conv_ring, "prof_ring"),
          "stem": (stem_phases, "prof_stem")}
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ bz = int(sys.argv[5])          # samples per step the passes were taken at: benc
 def total(fn, counter):
     tot, disp = 0.0, set()
     for r in csv.DictReader(open(fn)):
-        if ("conv_igemm" in r["Kernel_Name"] or "conv_wino" in r["Kernel_Name"] or "bottleneck_link" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
+        if ("conv_igemm" in r["Kernel_Name"] or "conv_wino" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
             tot += float(r["Counter_Value"])
             disp.add(r["Dispatch_Id"])
     return tot, len(disp)
@@ -24,9 +24,9 @@ def by_grid(fn, counter):
     """per (template instantiation, grid size): [dispatches, KB] -- which launch shapes carry the traffic"""
     g = {}
     for r in csv.DictReader(open(fn)):
-        if ("conv_igemm" in r["Kernel_Name"] or "conv_wino" in r["Kernel_Name"] or "bottleneck_link" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
+        if ("conv_igemm" in r["Kernel_Name"] or "conv_wino" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
             inst = r["Kernel_Name"].split("<")[1].split(">")[0].replace(" ", "") if "<" in r["Kernel_Name"] else "?"
-            key = ("sk" if "_sk_" in r["Kernel_Name"] else ("link" if "bottleneck_link" in r["Kernel_Name"] else ("wino" if "conv_wino" in r["Kernel_Name"] else ""))) + f"<{inst}> grid={r.get('Grid_Size', '?')}"
+            key = ("sk" if "_sk_" in r["Kernel_Name"] else ("wino" if "conv_wino" in r["Kernel_Name"] else "")) + f"<{inst}> grid={r.get('Grid_Size', '?')}"
             d = g.setdefault(key, [set(), 0.0])
             d[0].add(r["Dispatch_Id"])
             d[1] += float(r["Counter_Value"])
@@ -36,7 +36,7 @@ def by_grid(fn, counter):
 f, nf = total(fetch_csv, "FETCH_SIZE")
 w, nw = total(write_csv, "WRITE_SIZE")
 assert nf == nw and nf > 0, (nf, nw)
-res = {"workload": workload, "bz": bz, "kernel": "conv_igemm_f32_kernel + conv_igemm_sk_f32_kernel + conv_wino_f32_kernel + bottleneck_link_kernel", "dispatches": nf,
+res = {"workload": workload, "bz": bz, "kernel": "conv_igemm_f32_kernel + conv_igemm_sk_f32_kernel + conv_wino_f32_kernel", "dispatches": nf,
        "fetch_size_kb_sum": f, "write_size_kb_sum": w, "fetch_correction": 2.0,
        "hbm_gb_per_launch": (2.0 * f + w) * 1024 / nf / 1e9,
        "read_gb_per_launch": 2.0 * f * 1024 / nf / 1e9, "write_gb_per_launch": w * 1024 / nf / 1e9,

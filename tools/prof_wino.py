@@ -22,19 +22,12 @@ stream = torch.cuda.current_stream().cuda_stream
 for spec in sys.argv[1:]:
     vals = [int(v) for v in spec.split(",")]
     B, Cin, H, Cout = vals[:4]
-    C3 = vals[4] if len(vals) > 4 else 0           # > 0: the fused conv2 + conv3 launch (hands_bottleneck_wino_expand_f32)
     g = torch.Generator().manual_seed(1)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
     pc = pack_conv(w, torch.randn(Cout, generator=g), 1, 1, dev)
     x = torch.randn(B, H, H, Cin, device=dev)
     out = torch.empty(B, H, H, Cout, device=dev)
-    if C3:
-        from hands_amd.packing import add_operand_form
-        c3 = add_operand_form(pack_conv(torch.randn(C3, Cout, 1, 1, generator=g) / Cout ** 0.5, torch.randn(C3, generator=g), 1, 0, dev))
-        ident, out3 = torch.randn(B, H, H, C3, device=dev), torch.empty(B, H, H, C3, device=dev)
-        run = lambda: eng.bottleneck_wino_expand(L, pc, c3, x, out, ident, out3, B, H, H, stream)
-    else:
-        run = lambda: eng.conv(L, pc, x, B, H, H, out, True, stream)
+    run = lambda: eng.conv(L, pc, x, B, H, H, out, True, stream)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -58,7 +51,4 @@ for spec in sys.argv[1:]:
           f"(p10 {np.percentile(life, 10):.0f}, p90 {np.percentile(life, 90):.0f})")
     for name, v in (("setup + first DMA issue", setup), ("first barrier (DMA latency)", fill), ("channel stages", loop), ("epilogues", epi)):
         print(f"   {name:28s} {v.mean():9.0f}  ({100 * v.mean() / life.mean():4.1f} %)")
-    if p[:, 7].max() > 0:
-        ex = d(6, 7)
-        print(f"   expand phase (fused conv3)   {ex.mean():9.0f}  ({100 * ex.mean() / life.mean():4.1f} %)   [life above ends BEFORE it: total {life.mean() + ex.mean() + (p[:, 6] - p[:, 5]).mean():.0f}]")
     print(f"   stages take {loop.mean():.0f} cycles per workgroup; a stage is 32 MFMAs = 2048 matrix-pipe cycles per wave, x3 waves per SIMD = 6144")
