@@ -107,8 +107,12 @@ __global__ void kpe_concat_kernel(const float4* __restrict__ crop, const float4*
     float4 v;
     if (c < C4) {
       const float4 a = crop[pix * C4 + c];
-      const float4 g = glb[((long long)(b2 % Bg) * HW + p) * C4 + c];
-      v = make_float4(a.x + g.x, a.y + g.y, a.z + g.z, a.w + g.w);
+      if (glb) {                                  // use_glb_feat (model.py:263-264); nullptr: the crop features alone (:266-267)
+        const float4 g = glb[((long long)(b2 % Bg) * HW + p) * C4 + c];
+        v = make_float4(a.x + g.x, a.y + g.y, a.z + g.z, a.w + g.w);
+      } else {
+        v = a;
+      }
     } else {
       const int e0 = (c - C4) * 4;
       float r[4];
@@ -305,7 +309,7 @@ int hands_image_posenc_nhwc_f32(const float* img_nchw, const float* center_angle
 int hands_kpe_concat_f32(const float* crop, const float* glb, const float* center_angle,
                          const float* corner_angle, float* out, int B2, int Bg, int HW, int C,
                          int n_freq, hands_stream_t stream) {
-  if (!crop || !glb || !center_angle || !corner_angle || !out || B2 <= 0 || Bg <= 0 || C % 4 ||
+  if (!crop || !center_angle || !corner_angle || !out || B2 <= 0 || Bg <= 0 || C % 4 ||
       n_freq < 1 || n_freq > 16)
     return HANDS_EINVAL;
   const long long n = (long long)B2 * HW * (C / 4 + 5 * n_freq);

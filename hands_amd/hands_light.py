@@ -19,8 +19,8 @@ statement of ``forward`` runs as a hand-written gfx950 kernel from ``libhands_hi
 torch is used for parameter containers, device buffers and streams only.  Built configurations: resnet50,
 shared hand backbone, use_glb_feat, tf_decoder=False with pos_enc in {'center+corner_latent' (shipped default),
 'sinusoidal_cc', 'center', 'corner', 'center+corner', None}, ``no_crops`` (arctic_light), the grasp head with / without
-the global feature vector or absent; the remaining switches (separate_hands, tf_decoder, dense / pcl encodings, depth
-and renderer heads) raise ``NotImplementedError``.
+the global feature vector or absent, ``separate_hands``, ``regress_center_corner``, ``use_glb_feat=False``; the remaining
+switches (tf_decoder, dense / pcl encodings, depth and renderer heads) raise ``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -287,14 +287,19 @@ class HandsLight(EngineSwitches, nn.Module):
         self.no_crops = bool(get("no_crops", False))
         self.use_grasp_loss = bool(get("use_grasp_loss", False))
         self.use_glb_feat_w_grasp = bool(get("use_glb_feat_w_grasp", False))
+        self.separate_hands = bool(get("separate_hands", False))       # model.py:40-50: own trunk weights per side
+        self.regress_center_corner = bool(get("regress_center_corner", False))   # model.py:157-172, 426-433
+        self.use_glb_feat = bool(get("use_glb_feat", False))
         unsupported = {
             f"pos_enc={pos_enc!r}": self.enc_mode is None,     # 'pcl', 'perspective_correction', 'dense', 'dense_latent', 'cam_conv'
-            "separate_hands": bool(get("separate_hands", False)),
             "tf_decoder": bool(get("tf_decoder", False)),
             "use_depth_loss": bool(get("use_depth_loss", False)),
-            "regress_center_corner": bool(get("regress_center_corner", False)),
             "use_render_seg_loss": bool(get("use_render_seg_loss", False)),
-            "use_glb_feat=False": not get("use_glb_feat", False),
+            # the reference itself fails on these combinations (`features` / `feat_vec` undefined, model.py:191-201, 402-404;
+            # center_head on a 4-D map, :428)
+            "use_glb_feat=False with no_crops": not self.use_glb_feat and self.no_crops,
+            "use_glb_feat=False with use_glb_feat_w_grasp": (not self.use_glb_feat and self.use_grasp_loss and self.use_glb_feat_w_grasp),
+            "regress_center_corner with no_crops": self.regress_center_corner and self.no_crops,
         }
         bad = [k for k, v in unsupported.items() if v]
         if bad:
@@ -302,10 +307,14 @@ class HandsLight(EngineSwitches, nn.Module):
         self.n_freq = int(get("n_freq_pos_enc", 4))
         feat_dim = 2048
         self.feat_dim = feat_dim
-        self.backbone = ResNet50Params()
+        self.backbone = ResNet50Params()      # (the reference builds it even with use_glb_feat = False: same state_dict keys)
         # model.py:60-77: conv1 of the hand trunk takes the image-level encoding as extra input channels
         self.enc_channels = {1: 4, 2: 16, 3: 20}[IMAGE_ENC[pos_enc]] * self.n_freq if self.enc_mode == "image" else 0
-        self.hand_backbone = ResNet50Params(3 + self.enc_channels)
+        if self.separate_hands:
+            self.hand_backbone_r = ResNet50Params(3 + self.enc_channels)
+            self.hand_backbone_l = ResNet50Params(3 + self.enc_channels)
+        else:
+            self.hand_backbone = ResNet50Params(3 + self.enc_channels)
         self.head_r = HandHMR(feat_dim, True, 3)
         self.head_l = HandHMR(feat_dim, False, 3)
         fc_dim = feat_dim + (5 * 4 * self.n_freq if self.enc_mode == "latent" else 0)       # model.py:79-88
@@ -322,6 +331,11 @@ class HandsLight(EngineSwitches, nn.Module):
             self.grasp_classifier = nn.Sequential(
                 nn.Linear(gdim, 1024), nn.ReLU(inplace=True), nn.Linear(1024, 512),
                 nn.ReLU(inplace=True), nn.Linear(512, 128), nn.ReLU(inplace=True), nn.Linear(128, 9))
+        if self.regress_center_corner:
+            mk = lambda n: nn.Sequential(nn.Linear(feat_dim, 512), nn.ReLU(inplace=True), nn.Linear(512, 128),
+                                         nn.ReLU(inplace=True), nn.Linear(128, n))
+            self.corner_head = mk(8)
+            self.center_head = mk(2)
         self.mode = "train"
         self.img_res = img_res
         self.focal_length = focal_length
@@ -404,9 +418,19 @@ class HandsLight(EngineSwitches, nn.Module):
     def _pack(self, dev):
         cpu = lambda t: t.detach().cpu()
         F = self.feat_dim
-        P = {"backbone": self._pack_trunk(self.backbone, dev),
-             "hand_backbone": self._pack_trunk(self.hand_backbone, dev),
-             "head_r": self._pack_head(self.head_r, dev), "head_l": self._pack_head(self.head_l, dev)}
+        P = {"head_r": self._pack_head(self.head_r, dev), "head_l": self._pack_head(self.head_l, dev)}
+        if self.use_glb_feat:
+            P["backbone"] = self._pack_trunk(self.backbone, dev)
+        if not self.no_crops:
+            if self.separate_hands:
+                P["hand_backbone_r"] = self._pack_trunk(self.hand_backbone_r, dev)
+                P["hand_backbone_l"] = self._pack_trunk(self.hand_backbone_l, dev)
+            else:
+                P["hand_backbone"] = self._pack_trunk(self.hand_backbone, dev)
+        if self.regress_center_corner:
+            for nm, head in (("cc_center", self.center_head), ("cc_corner", self.corner_head)):
+                P[nm] = [pack_linear(cpu(head[0].weight), cpu(head[0].bias), dev), pack_linear(cpu(head[2].weight), cpu(head[2].bias), dev),
+                         pack_linear(cpu(head[4].weight), cpu(head[4].bias), dev, n_total=8)]
         fc = self.feature_conv
         P["fc0"] = pack_conv(cpu(fc[0].weight), None, 1, 0, dev)
         P["fc2"] = pack_conv(cpu(fc[2].weight), None, 1, 0, dev)
@@ -575,18 +599,20 @@ class HandsLight(EngineSwitches, nn.Module):
                 prev_tail = self._ws.get(f"tail_done{q}")
                 if prev_tail is not None:
                     main.wait_event(prev_tail)
-        featg = buf(f"feat_g{par}", bz * 49 * F)
+        featg = buf(f"feat_g{par}", bz * 49 * F) if self.use_glb_feat else None
         feath = buf(f"feat_h{par}", B2 * 49 * F) if not self.no_crops else None
         gch, hch = self.trunk_chunks if self.engine.overlap else (1, 1)
         if self.no_crops:          # model.py:199-201: no hand trunks; the global job may as well be cut in two
             gch, hch = (2 if self.engine.overlap else 1), 0
-        gch, hch = max(1, min(gch, bz)), min(hch, B2)
+        if self.separate_hands and hch:
+            hch = 2                # one job per side: the sides have their own weights (model.py:226-228)
+        gch, hch = (max(1, min(gch, bz)) if self.use_glb_feat else 0), min(hch, B2)
         center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0) if self.enc_mode != "none" else None
         corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0) if self.enc_mode != "none" else None
         wide = None
         if self.enc_mode == "image" and not self.no_crops:
             # model.py:203-218: cat([crop, enc repeated over the pixels]) as the NHWC input of the widened conv1
-            Cp = P["hand_backbone"]["stem_wide"].Cin
+            Cp = P["hand_backbone_r" if self.separate_hands else "hand_backbone"]["stem_wide"].Cin
             wide = buf("wide_in", B2 * res * res * Cp)
             mode = IMAGE_ENC[self.pos_enc]
             for side, im in enumerate((r_img, l_img)):
@@ -607,7 +633,7 @@ class HandsLight(EngineSwitches, nn.Module):
                     segs.append((r_img, lo, min(hi, bz) - lo))
                 if hi > bz:
                     segs.append((l_img, max(lo, bz) - bz, hi - max(lo, bz)))
-            jobs.append((P["hand_backbone"], segs, lo, hi - lo, feath))
+            jobs.append((P[("hand_backbone_r", "hand_backbone_l")[c]] if self.separate_hands else P["hand_backbone"], segs, lo, hi - lo, feath))
         ev0 = torch.cuda.Event()
         ev0.record(main)
         fh = fw = 7
@@ -669,8 +695,8 @@ class HandsLight(EngineSwitches, nn.Module):
                 # -- KPE concat (model.py:258-271, 288-304) ------------------------------------------------
                 Cc = F + 20 * self.n_freq
                 cat = buf("cat", B2 * HW * Cc)
-                check(L.hands_kpe_concat_f32(ptr(feath), ptr(featg), ptr(center), ptr(corner), ptr(cat), B2, bz,
-                                             HW, F, self.n_freq, stream), "kpe_concat")
+                check(L.hands_kpe_concat_f32(ptr(feath), ptr(featg) if self.use_glb_feat else None, ptr(center), ptr(corner),
+                                             ptr(cat), B2, bz, HW, F, self.n_freq, stream), "kpe_concat")
             else:
                 cat = feath            # pos_enc None / image-level: feature_conv reads the crop features as they are
             # -- feature_conv (model.py:91-101, 313-314) -> HMR state rows ---------------------------
@@ -733,8 +759,24 @@ class HandsLight(EngineSwitches, nn.Module):
         output = run_mano_heads(L, P["mano_r"], P["mano_l"], rot_m, shape_m, cam_m, caminit_m, K,
                                 float(self.img_res), bz, stream, buf, self.engine)
 
+        # -- center / corner regression from the feature_conv vectors (model.py:426-433) -------------------
+        extra = None
+        if self.regress_center_corner:
+            extra = xdict()
+            for nm, key in (("cc_center", "center"), ("cc_corner", "corner")):
+                l0, l1, l2 = P[nm]
+                h1, h2 = buf("cc_h1", B2 * 512), buf("cc_h2", B2 * 128)
+                o = torch.empty(B2, 8, device=dev)
+                self.engine.conv(L, l0, state, B2, 1, 1, h1, True, stream, in_ps=ld, splitk=True)
+                self.engine.conv(L, l1, h1, B2, 1, 1, h2, True, stream, splitk=True)
+                self.engine.conv(L, l2, h2, B2, 1, 1, o, False, stream)
+                n = 2 if key == "center" else 8
+                extra[key + ".r"] = o[:bz, :n].contiguous()
+                extra[key + ".l"] = o[bz:, :n].contiguous()
         # -- grasp classifier on the UN-flipped HMR outputs (model.py:401-411) -------------------
         if not self.use_grasp_loss:
+            if extra is not None:
+                output.merge(extra)
             return output
         Fg = F if self.use_glb_feat_w_grasp else 0
         gld = P["g0"].Cin
@@ -751,4 +793,6 @@ class HandsLight(EngineSwitches, nn.Module):
         grasp["grasp.r"] = g4[:bz, :9].contiguous()
         grasp["grasp.l"] = g4[bz:, :9].contiguous()
         output.merge(grasp)
+        if extra is not None:          # model.py:426-433: merged after the grasp outputs
+            output.merge(extra)
         return output

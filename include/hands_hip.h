@@ -204,7 +204,8 @@ int hands_image_posenc_nhwc_f32(const float* img_nchw, const float* center_angle
 /* out[b2, p, :] = cat(crop[b2,p,:] + glb[b2 % Bg, p, :], center_enc(b2), corner_enc(b2)).
  * crop holds the right-hand samples then the left-hand samples (2*Bg rows); encodings are the
  * reference's [sin(2^k a), cos(2^k a)] laid out (L, c, 2).  model.py:258-271, 444-460.
- * center_angle (2*Bg, 2), corner_angle (2*Bg, 8); out channels = C + 4*L + 16*L. */
+ * center_angle (2*Bg, 2), corner_angle (2*Bg, 8); out channels = C + 4*L + 16*L.
+ * glb == NULL: use_glb_feat = False, the crop features are concatenated as they are (model.py:266-267). */
 int hands_kpe_concat_f32(const float* crop, const float* glb, const float* center_angle,
                          const float* corner_angle, float* out, int B2, int Bg, int HW, int C,
                          int n_freq, hands_stream_t stream);

@@ -334,14 +334,17 @@ def image_level_input(img, center_angle, corner_angle, mode, n_freq=4):
 
 def hands_light_forward(sd, asset_r, asset_l, inputs, meta_info, img_res=224, n_freq=4,
                         return_intermediates=False, pos_enc_mode="center+corner_latent", no_crops=False,
-                        use_grasp_loss=True, use_glb_feat_w_grasp=True):
+                        use_grasp_loss=True, use_glb_feat_w_grasp=True, separate_hands=False, regress_center_corner=False,
+                        use_glb_feat=True):
     """model.py:187-437 with use_glb_feat=True, shared hand backbone, tf_decoder=False.  ``pos_enc_mode``:
     'center+corner_latent' | 'sinusoidal_cc' (same code path, model.py:258-271 / 288-304), 'center' | 'corner' |
     'center+corner' (image level, model.py:203-218) or None."""
     K = meta_info["intrinsics"]
     bz = inputs["img"].shape[0]
-    features = resnet50_trunk(inputs["img"], sd, "backbone")                      # model.py:193
-    feat_vec = features.view(bz, features.shape[1], -1).sum(dim=2)                # model.py:196 (SUM)
+    features = feat_vec = None
+    if use_glb_feat:                                                              # model.py:191-196
+        features = resnet50_trunk(inputs["img"], sd, "backbone")                  # model.py:193
+        feat_vec = features.view(bz, features.shape[1], -1).sum(dim=2)            # model.py:196 (SUM)
     r_feat = l_feat = None
     if no_crops:                                                                  # model.py:199-201, 316-318
         # HandHMR.forward(features, use_pool=True): nn.AdaptiveAvgPool2d(1) (hand_hmr.py:73-78)
@@ -352,11 +355,12 @@ def hands_light_forward(sd, asset_r, asset_l, inputs, meta_info, img_res=224, n_
             l_in = image_level_input(inputs["l_img"], inputs["l_center_angle"], inputs["l_corner_angle"], pos_enc_mode, n_freq)
         else:
             r_in, l_in = inputs["r_img"], inputs["l_img"]
-        r_feat = resnet50_trunk(r_in, sd, "hand_backbone")                        # model.py:238
-        l_feat = resnet50_trunk(l_in, sd, "hand_backbone")                        # model.py:239
+        r_feat = resnet50_trunk(r_in, sd, "hand_backbone_r" if separate_hands else "hand_backbone")   # model.py:226-239
+        l_feat = resnet50_trunk(l_in, sd, "hand_backbone_l" if separate_hands else "hand_backbone")
         if pos_enc_mode in ("center+corner_latent", "sinusoidal_cc"):
-            r_cat = assemble_features(r_feat, features, inputs["r_center_angle"], inputs["r_corner_angle"], n_freq)
-            l_cat = assemble_features(l_feat, features, inputs["l_center_angle"], inputs["l_corner_angle"], n_freq)
+            glb = features if use_glb_feat else torch.zeros_like(r_feat)          # model.py:263-267 (x + 0 == x exactly)
+            r_cat = assemble_features(r_feat, glb, inputs["r_center_angle"], inputs["r_corner_angle"], n_freq)
+            l_cat = assemble_features(l_feat, glb, inputs["l_center_angle"], inputs["l_corner_angle"], n_freq)
         else:
             r_cat, l_cat = r_feat, l_feat            # the global features are NOT added on these routes (model.py:241-304)
         r_vec = feature_conv(r_cat, sd)                                           # model.py:313
@@ -401,6 +405,13 @@ def hands_light_forward(sd, asset_r, asset_l, inputs, meta_info, img_res=224, n_
         gf = feat_vec if use_glb_feat_w_grasp else None
         out["grasp.r"] = grasp_classifier(hmr_r["shape"], hmr_r["pose"], gf, sd)
         out["grasp.l"] = grasp_classifier(hmr_l["shape"], hmr_l["pose"], gf, sd)
+    if regress_center_corner:                                                     # model.py:426-433
+        def head3(x, p):
+            for i in (0, 2):
+                x = F.relu(F.linear(x, sd[f"{p}.{i}.weight"], sd[f"{p}.{i}.bias"]))
+            return F.linear(x, sd[f"{p}.4.weight"], sd[f"{p}.4.bias"])
+        out["center.r"], out["center.l"] = head3(r_vec, "center_head"), head3(l_vec, "center_head")
+        out["corner.r"], out["corner.l"] = head3(r_vec, "corner_head"), head3(l_vec, "corner_head")
     if return_intermediates:
         inter = {"features": features, "feat_vec": feat_vec, "r_feat": r_feat, "l_feat": l_feat,
                  "r_vec": r_vec, "l_vec": l_vec, "hmr_r": hmr_r, "hmr_l": hmr_l}

@@ -8,7 +8,7 @@ import torch
 import hands_amd
 from hands_amd.weights import synthetic_inputs
 
-SWITCH_CASES = ("arctic", "sinusoidal_cc", "center", "corner", "center_corner", "plain")
+SWITCH_CASES = ("arctic", "sinusoidal_cc", "center", "corner", "center_corner", "plain", "separate", "noglb")
 
 
 def load_case(golden_dir, name):
@@ -24,4 +24,6 @@ def load_case(golden_dir, name):
 
 def oracle_kwargs(cfg):
     return dict(pos_enc_mode=cfg.get("pos_enc", "center+corner_latent"), no_crops=cfg.get("no_crops", False),
-                use_grasp_loss=cfg.get("use_grasp_loss", True), use_glb_feat_w_grasp=cfg.get("use_glb_feat_w_grasp", True))
+                use_grasp_loss=cfg.get("use_grasp_loss", True), use_glb_feat_w_grasp=cfg.get("use_glb_feat_w_grasp", True),
+                separate_hands=cfg.get("separate_hands", False), regress_center_corner=cfg.get("regress_center_corner", False),
+                use_glb_feat=cfg.get("use_glb_feat", True))

@@ -977,7 +977,7 @@ def test_splitk_n_is_deterministic_and_right(case):
     assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("name", ["arctic", "sinusoidal_cc", "center", "corner", "center_corner", "plain"])
+@pytest.mark.parametrize("name", ["arctic", "sinusoidal_cc", "center", "corner", "center_corner", "plain", "separate", "noglb"])
 def test_switch_configurations_vs_reference_fixtures(golden_dir, name):
     """Non-default HandsLight switches through the HIP path against what the REFERENCE produced for them
     (tests/golden/make_golden_switches.py): `no_crops` (arctic_light: hands_avgpool_nhwc_f32 -> both heads), the image-level
@@ -994,7 +994,7 @@ def test_switch_configurations_vs_reference_fixtures(golden_dir, name):
     for k in keys:
         ref, got = d["out/" + k], out[k].cpu().numpy()
         assert got.shape == ref.shape, k
-        if k.startswith("grasp"):
+        if k.startswith(("grasp", "center.", "corner.")):       # MLP read-outs of O(1-10) activations
             np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4, err_msg=k)
         elif ".cam." in k or k.startswith("mano.cam_t."):
             np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5, err_msg=k)

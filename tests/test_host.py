@@ -256,8 +256,8 @@ def test_unsupported_switches_fail_loudly():
         hands_amd.HandsLight(args=type(hands_amd.DEFAULT_ARGS)(a))
     with pytest.raises(NotImplementedError):
         hands_amd.HandsLight(backbone="resnet18")
-    for bad in (dict(pos_enc="dense_latent"), dict(pos_enc="pcl"), dict(separate_hands=True), dict(use_depth_loss=True),
-                dict(use_glb_feat=False), dict(regress_center_corner=True)):
+    for bad in (dict(pos_enc="dense_latent"), dict(pos_enc="pcl"), dict(use_depth_loss=True), dict(use_glb_feat=False),
+                dict(regress_center_corner=True, no_crops=True)):
         with pytest.raises(NotImplementedError):
             hands_amd.HandsLight(args=type(hands_amd.DEFAULT_ARGS)(dict(hands_amd.DEFAULT_ARGS, **bad)))
     # built non-default switches construct (parity: tests/test_oracle_golden.py, tests/test_gpu_parity.py)

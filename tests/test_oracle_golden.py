@@ -116,7 +116,7 @@ def test_state_dict_keys_match_reference(golden_dir, recipe_model):
     assert mine == ref and len(ref) == 681
 
 
-@pytest.mark.parametrize("name", ["arctic", "sinusoidal_cc", "center", "corner", "center_corner", "plain"])
+@pytest.mark.parametrize("name", ["arctic", "sinusoidal_cc", "center", "corner", "center_corner", "plain", "separate", "noglb"])
 def test_switch_configurations_match_reference(golden_dir, name):
     """Non-default HandsLight switches (model.py:40-47,60-86,127,199-232,316-318,401-411): the host mirror builds the
     reference's parameter tree for the configuration (names + shapes from the reference's own state_dict) and the oracle
@@ -135,10 +135,11 @@ def test_switch_configurations_match_reference(golden_dir, name):
     out = O.hands_light_forward(sd, synthetic_mano_asset(True), synthetic_mano_asset(False), inputs, meta_info,
                                 **oracle_kwargs(cfg))
     keys = sorted(k[4:] for k in d.files if k.startswith("out/"))
-    assert sorted(out.keys()) == keys and len(keys) == (22 if cfg.get("use_grasp_loss", True) else 20)
+    assert sorted(out.keys()) == keys and len(keys) == (22 if cfg.get("use_grasp_loss", True) else 20) + (4 if cfg.get("regress_center_corner") else 0)
     for k in keys:
-        tol = 1e-4 if k.startswith("grasp") else 2e-5
-        np.testing.assert_allclose(out[k].numpy(), d["out/" + k], rtol=tol if (".cam." in k or "cam_t" in k or k.startswith("grasp")) else 0,
+        mlp = k.startswith(("grasp", "center.", "corner."))
+        tol = 1e-4 if mlp else 2e-5
+        np.testing.assert_allclose(out[k].numpy(), d["out/" + k], rtol=tol if (".cam." in k or "cam_t" in k or mlp) else 0,
                                    atol=tol, err_msg=k)
     for hn in "rl":
         assert np.abs(out[f"mano.vertices.{hn}"].numpy() - d[f"out/mano.vertices.{hn}"]).max() < 1e-6
