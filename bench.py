@@ -203,6 +203,20 @@ def pmc_traffic_per_launch(workload, bz):
     return None, None
 
 
+def pmc_shipped_gb_per_step(workload, bz):
+    """(GB per forward over the conv launches of the SHIPPED mode, source file) from the newest committed shipped-mode counter
+    summary taken at this batch size (tools/profile_round.sh: HANDS_BENCH_SHIPPED_ONLY passes), or (None, None)."""
+    for rnd in ("r04",):
+        fn = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{workload}_bz{bz}_shipped.json")
+        try:
+            d = json.load(open(fn))
+            if int(d.get("bz", -1)) == int(bz) and d.get("gb_per_forward"):
+                return round(d["gb_per_forward"], 3), os.path.relpath(fn, ROOT)
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
+
+
 class Ctx:
     """Rank context: torch.distributed state + device."""
 
@@ -428,6 +442,11 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         "ms_per_step": res["ms_per_step"], "path_tflops": round(path_tf, 2),
         "path_frac_of_fp32_mfma_peak": round(path_tf / FP32_MFMA_PEAK_TFLOPS, 4)}
 
+    if os.environ.get("HANDS_BENCH_SHIPPED_ONLY") == "1":
+        # developer switch for counter passes (tools/pmc_positions.sh): only the shipped-mode forwards run in this process, so
+        # every dispatch rocprofv3 sees is a launch of the mode `value` is measured in
+        res["roofline"] = None
+        return res, model, sd_cpu
     # ---- the same model in one-stream mode: wall clock + every MFMA launch bracketed by events -------
     model.overlap_trunks = False
     n_ser = max(2, min(steps, 5))
@@ -518,6 +537,8 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
     ig_ms = sum(d["ms"] for d in igemm) / n_prof
     ig_flop = sum(d["flop"] for d in igemm) / n_prof
     traffic, traffic_src = pmc_traffic_per_launch(workload, bz)
+    ship_gb, ship_src = pmc_shipped_gb_per_step(workload, bz)
+    fam_alg_gb_step = sum(d["bytes"] for d in fam) / n_prof / 1e9
     if math == "bf16x3":
         # this mode runs six v_mfma_f32_32x32x16_bf16 per k-16 step where the exact path runs eight fp32 MFMAs: its
         # ceiling in fp32-EQUIVALENT FLOPs is the dense bf16 peak / 6, not the fp32-MFMA peak
@@ -560,6 +581,11 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         "traffic": traffic, "traffic_unit": "GB/launch", "traffic_source": traffic_src,
         "traffic_over_algorithmic": round(traffic / fam_alg_gb, 3) if traffic and fam_alg_gb > 0 else None,
         "algorithmic_gb_per_conv_launch": round(fam_alg_gb, 4),
+        # the same counters over the launches of the SHIPPED mode (plain kernels on several streams; the one-stream mode above
+        # runs stream-K launches, whose sequential n-tiles re-read their activation panel): GB per forward over all conv launches
+        "traffic_shipped_gb_per_step": ship_gb, "traffic_shipped_source": ship_src,
+        "algorithmic_gb_per_step": round(fam_alg_gb_step, 3),
+        "traffic_shipped_over_algorithmic": round(ship_gb / fam_alg_gb_step, 3) if ship_gb and fam_alg_gb_step > 0 else None,
         "stream_k": {"engine_setting": sk, "used_in_this_serial_pass": any(k == "conv_igemm_sk_f32_kernel" for k in per),
                      "launches_per_step": per.get("conv_igemm_sk_f32_kernel", {"launches": 0})["launches"] // n_prof},
         "timing": f"hip_events_per_launch_median_of_{n_prof}",
@@ -792,7 +818,8 @@ def measure_lbs(ctx, bz, steps, warmup, with_cpu=True):
 # ------------------------------------------------------------------------------------------------------
 HEADLINE_LIMIT = 4096
 ROOFLINE_KEYS = ("bound", "mode", "kernel", "achieved", "peak", "unit", "frac", "executed_frac", "dominant", "frac_on_own_roof",
-                 "by_bound", "traffic", "traffic_over_algorithmic", "kernel_ms_per_step", "step_ms_same_mode",
+                 "by_bound", "traffic", "traffic_over_algorithmic", "traffic_shipped_over_algorithmic", "kernel_ms_per_step",
+                 "step_ms_same_mode",
                  "launches_per_step", "us_per_launch", "device_ms_per_step", "hbm_gbs")
 CPU_KEYS = ("value", "unit", "cores", "kind", "bz", "sample")
 PARITY_KEYS = ("mpjpe_vs_ref_mm", "max_vertex_err_m", "checked_hands", "worst_vertex_err_m", "worst_seed", "sweep_seeds", "bar_m")
