@@ -90,6 +90,23 @@ def test_bench_at_the_drivers_arguments_two_ranks():
     assert d["roofline"]["frac"] > 0 and d["allgather_us"] > 0
 
 
+def test_bench_under_torchrun_two_ranks():
+    """The driver's N > 1 command: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- every process is a rank (no launcher), rank 0 prints the one headline.  Dry run on the
+    1-GPU box (both ranks on cuda:0, gloo staging the device tensors)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(HANDS_BENCH_SHARE_GPU="1", HANDS_BENCH_BACKEND="gloo", HANDS_BENCH_GLOO_DEVICE="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps",
+                        "3", "--warmup", "1", "--bz", "8", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and p.stdout.strip().splitlines()[-1] == lines[0]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["launched_by"] == "torchrun" and d["config"]["rccl_ranks"] == 2
+    assert d["config"]["global_batch"] == 16 and d["value"] > 0 and d["allgather_us"] > 0
+
+
 def test_bench_hamer_light_two_rank_dry_run():
     """`bench.py --workload hamer_light --gpus 2` (BASELINE configs[2], weak scaling; reduced to bz=4 per rank here)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
