@@ -9,6 +9,7 @@ loudly here instead of silently measuring something else.
                                          workgroup (tools/prof_clock.py)
   python tools/instrument.py ring    -> build_ab/prof_ring.so    conv_igemm: the middle workgroup of every plain launch stamps
                                          both clocks into a ring (tools/prof_ring.py)
+  python tools/instrument.py mano    -> build_ab/prof_mano.so    mano_heads_kernel: pose / blend / skinning / write-back time per wave (tools/prof_mano.py)
   python tools/instrument.py attn    -> build_ab/prof_attn.so    attention_kernel: seven phase stamps per wave (tools/prof_attn.py)
   python tools/instrument.py stem    -> build_ab/prof_stem.so    stem_pool_planar_kernel: entry / after the patch fill / after
                                          the GEMM / exit (tools/stem_prof.py)
@@ -24,6 +25,7 @@ CONV = os.path.join(ROOT, "hands_amd", "csrc", "conv_igemm.hip")
 STEM = os.path.join(ROOT, "hands_amd", "csrc", "stem_pool.hip")
 WINO = os.path.join(ROOT, "hands_amd", "csrc", "conv_wino.hip")
 TRANS = os.path.join(ROOT, "hands_amd", "csrc", "transformer.hip")
+MANO = os.path.join(ROOT, "hands_amd", "csrc", "mano_lbs.hip")
 
 
 def sub(s, old, new, what):
@@ -196,7 +198,44 @@ namespace {
     return head + body, "transformer.hip"
 
 
-KINDS = {"attn": (attn_phases, "prof_attn"), "wino": (wino_phases, "prof_wino"), "tile": (conv_tile_timeline, "prof_tile"), "clock": (conv_clock, "prof_clock"), "ring": (conv_ring, "prof_ring"),
+def mano_phases():
+    """mano_heads_kernel: s_memrealtime of lane 0 of every wave at entry / after the pose + FK phase / accumulated over the
+    chunks: blend product (+ its barrier), skinning product, write-back (+ barrier) / exit; slot 7 = HW_ID | XCC_ID << 32
+    (tools/prof_mano.py)"""
+    s = open(MANO).read()
+    s = sub(s, "namespace {\n", """__device__ unsigned long long g_mprof[16384 * 8];
+extern "C" int hands_debug_mprof(void* dst) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_mprof), sizeof(unsigned long long) * 16384 * 8);
+  return 0;
+}
+namespace {
+""", "globals")
+    # the stamps cost ~6 registers (124 -> 130 = 3 instead of 4 waves per SIMD): hold the instrumented copy at 128 (a few spills)
+    # so that it has the production kernel's residency
+    s = sub(s, "__launch_bounds__(256, 2) mano_heads_kernel", "__launch_bounds__(256, 4) mano_heads_kernel", "bounds")
+    i = s.index("mano_heads_kernel(ManoHeadsArgs a) {")
+    head, body = s[:i], s[i:]
+    now = "(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__builtin_amdgcn_s_memrealtime())"   # uniform 32-bit ticks: scalar registers
+    fence = "__builtin_amdgcn_sched_barrier(0);"
+    body = sub(body, "  const int B = a.B;\n", "  const int B = a.B;\n  unsigned t_bl = 0, t_sk = 0, t_wb = 0, t_x = 0;\n"
+               f"  {fence} const unsigned t_in = {now}; {fence}\n", "entry")
+    body = sub(body, "  // ---- phase 2 + 3 per chunk", f"  {fence} const unsigned t_pose = {now}; t_x = t_pose; {fence}\n  // ---- phase 2 + 3 per chunk", "pose")
+    body = sub(body, "    __syncthreads();\n#endif\n#if !(defined(HANDS_MANO_ABL) && HANDS_MANO_ABL == 2)",
+               f"    __syncthreads();\n    {fence} {{ const unsigned t = {now}; t_bl += t - t_x; t_x = t; }} {fence}\n#endif\n#if !(defined(HANDS_MANO_ABL) && HANDS_MANO_ABL == 2)", "blend")
+    body = sub(body, "#if !(defined(HANDS_MANO_ABL) && HANDS_MANO_ABL == 4)   // timing-only ablation 4: no vertex write-back",
+               f"    {fence} {{ const unsigned t = {now}; t_sk += t - t_x; t_x = t; }} {fence}\n#if !(defined(HANDS_MANO_ABL) && HANDS_MANO_ABL == 4)   // timing-only ablation 4: no vertex write-back", "skin")
+    body = sub(body, "    __syncthreads();      // the stage is rewritten by the next chunk's GEMM\n",
+               f"    __syncthreads();      // the stage is rewritten by the next chunk's GEMM\n    {fence} {{ const unsigned t = {now}; t_wb += t - t_x; t_x = t; }} {fence}\n", "write-back")
+    body = sub(body, "      d2[1] = 2.0f * (hy / hz) / a.img_res - 1.0f;\n    }\n  }\n}\n\n}  // namespace",
+               "      d2[1] = 2.0f * (hy / hz) / a.img_res - 1.0f;\n    }\n  }\n"
+               "  const int pslot = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);\n"
+               f"  {fence} if ((threadIdx.x & 63) == 0 && pslot < 16384) {{ unsigned long long* o = g_mprof + pslot * 8; o[0] = t_in; o[1] = t_pose; o[2] = t_bl; o[3] = t_sk; o[4] = t_wb; o[5] = {now}; o[6] = c1 - c0;\n"
+               "    o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); }\n}\n\n}  // namespace", "exit")
+    return head + body, "mano_lbs.hip"
+
+
+KINDS = {"mano": (mano_phases, "prof_mano"), "attn": (attn_phases, "prof_attn"), "wino": (wino_phases, "prof_wino"), "tile": (conv_tile_timeline, "prof_tile"), "clock": (conv_clock, "prof_clock"), "ring": (conv_ring, "prof_ring"),
          "stem": (stem_phases, "prof_stem")}
 
 if __name__ == "__main__":
