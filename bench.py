@@ -16,10 +16,11 @@
   strong scaling.
 * Inputs are resident in HBM before the timed region; outputs stay on the device.
 
-Output (rank 0): the headline is the LAST stdout line, one JSON object below 4 KB (``compact_headline``); at N=1 the
-default run first prints one short JSON line per extra measurement (``{"also": "<name>", ...}``: BASELINE configs 3-5 and
-the separately reported arithmetic modes, each with roofline + cpu_baseline + parity); the per-kernel / per-launch-shape
-tables of everything go to ``gpurun_out/bench_details.json``.  What the keys mean is DESIGN.md section 5:
+Output (rank 0): stdout carries exactly ONE line, the headline: a JSON object below 4 KB (``compact_headline``).  At N=1 the
+default run also writes one short JSON line per extra measurement to STDERR (``{"also": "<name>", ...}``: BASELINE configs
+3-5 and the separately reported arithmetic modes, each with roofline + cpu_baseline + parity; the headline carries their
+values as ``also: {name: hands/s}``); the per-kernel / per-launch-shape tables of everything go to
+``gpurun_out/bench_details.json``.  What the keys mean is DESIGN.md section 5:
 ``roofline`` covers the MFMA kernels (conv_igemm_f32 family + conv_wino_f32 + the fused stem): achieved = algorithmic
 FLOPs of all their launches in one step / the summed duration of those launches, each bracketed by HIP events on the
 launch stream in ``mode: "serial"`` (one HIP stream, every launch alone on the chip -- the mode the rocprofv3 per-kernel
@@ -812,8 +813,8 @@ def measure_lbs(ctx, bz, steps, warmup, with_cpu=True):
 
 
 # ------------------------------------------------------------------------------------------------------
-# output: short lines.  The driver keeps the last 8000 characters of stdout and parses the LAST line:
-# the headline is printed last and stays below 4 KB; every extra measurement is its own short line before it; tables
+# output: short lines.  The driver keeps the last 8000 characters of stdout: stdout is ONE line, the headline,
+# below 4 KB; every extra measurement is its own short line on stderr; tables
 # (per kernel, per launch shape, by-bz CPU timings) go to gpurun_out/bench_details.json; prose lives in DESIGN.md section 5.
 # ------------------------------------------------------------------------------------------------------
 HEADLINE_LIMIT = 4096
@@ -849,7 +850,7 @@ def compact_entry(full):
 
 
 def compact_headline(full, also=None, details_path=None):
-    """The LAST stdout line: < HEADLINE_LIMIT characters, whatever the measurements returned."""
+    """THE stdout line: < HEADLINE_LIMIT characters, whatever the measurements returned."""
     line = compact_entry(full)
     if also:
         line["also"] = {k: (v.get("value") if isinstance(v, dict) and "error" not in v else "error") for k, v in also.items()
@@ -945,8 +946,11 @@ def main():
         t_also = time.perf_counter()
 
         def emit_also(key, r):
+            # one short line per extra measurement -- on STDERR: stdout carries exactly ONE JSON line, the headline, so that
+            # whichever line of stdout a harness parses (first, last, only) is the BASELINE metric on its config
             also[key] = r
-            print(json.dumps(dict(compact_entry(r), also=key)), flush=True)
+            sys.stderr.write(json.dumps(dict(compact_entry(r), also=key)) + "\n")
+            sys.stderr.flush()
 
         # name, bz, steps, warmup, parity bz.  *_bf16x3: separately reported arithmetic mode, never the headline value;
         # *_winograd_all: HandOccNet's opt-in scope
@@ -990,7 +994,7 @@ def main():
         full["also_seconds"] = round(time.perf_counter() - t_also, 1)
     if rank0:
         details = write_details(full, also)
-        print(json.dumps(compact_headline(full, also, details)), flush=True)       # the headline: LAST line, < 4 KB
+        print(json.dumps(compact_headline(full, also, details)), flush=True)       # the headline: the only stdout line, < 4 KB
     ctx.close()
 
 

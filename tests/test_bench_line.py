@@ -1,6 +1,6 @@
-"""bench.py's output contract: the headline is the LAST stdout line and stays below 4 KB whatever
+"""bench.py's output contract: stdout is ONE line, the headline, and it stays below 4 KB whatever
 the measurements returned (round 3's single 23 KB line left the driver's record unparsed); every extra measurement is
-its own short line.  Plus the rank-affinity helper (sysfs only).  CPU only: the lines are built from canned results."""
+its own short line (on stderr).  Plus the rank-affinity helper (sysfs only).  CPU only: the lines are built from canned results."""
 import importlib.util
 import json
 import os

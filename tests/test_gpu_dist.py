@@ -65,7 +65,7 @@ def test_bench_launcher_starts_its_own_ranks():
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["global_batch"] == 16
     assert d["config"]["launched_by"] == "bench.py launcher" and d["value"] > 0
     assert d["roofline"]["kernel_ms_per_step"] <= d["roofline"]["step_ms_same_mode"]
-    assert p.stdout.splitlines()[-1] == lines[0] and len(lines[0]) < 4096      # the headline is the LAST line, short
+    assert p.stdout.splitlines()[-1] == lines[0] and len(lines[0]) < 4096      # stdout is the headline alone, short
     # N > 1 keys (VERDICT r3 item 6 i): the collective alone, the host side of a step, every rank's own rate
     assert d["allgather_us"] > 0 and d["host_enqueue_ms_per_step"] > 0
     assert 0 < d["per_rank_hands_per_sec"]["min"] <= d["per_rank_hands_per_sec"]["max"]
@@ -88,6 +88,24 @@ def test_bench_at_the_drivers_arguments_two_ranks():
     assert d["config"]["per_gpu_batch"] == 256 and d["config"]["global_batch"] == 512 and d["config"]["rccl_ranks"] == 2
     assert d["value"] > 0 and abs(d["value"] - 2 * 2 * 256 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
     assert d["roofline"]["frac"] > 0 and d["allgather_us"] > 0
+
+
+def test_bench_default_run_prints_one_stdout_line():
+    """`python bench.py` (N = 1, with the extra measurements of configs 3-5): stdout is exactly ONE line -- the headline with
+    roofline, cpu_baseline and parity -- below 4 KB; the extra measurements are short JSON lines on stderr."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--bz", "16"], env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = p.stdout.strip().splitlines()
+    assert len(out) == 1 and len(out[0]) < 4096
+    d = json.loads(out[0])
+    assert d["n_gpus"] == 1 and d["metric"] == "hands/sec" and d["config"]["per_gpu_batch"] == 16 and d["dtype"] == "f32"
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    assert d["parity"]["max_vertex_err_m"] < 1e-6 and d["parity"]["worst_vertex_err_m"] < 1e-6
+    also = [json.loads(l) for l in p.stderr.splitlines() if l.startswith("{") and '"also"' in l]
+    assert {a["also"] for a in also} >= {"hamer_light", "handoccnet_light", "mano_lbs"} and set(d["also"]) == {a["also"] for a in also}
+    assert all(len(json.dumps(a)) < 2048 for a in also)
 
 
 def test_bench_under_torchrun_two_ranks():
