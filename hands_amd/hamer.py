@@ -185,10 +185,10 @@ class HAMER(EngineSwitches, nn.Module):
         args = args if args is not None else HAMER_DEFAULT_ARGS
         get = args.get if hasattr(args, "get") else (lambda k, d=None: getattr(args, k, d))
         self.args = args
-        if get("pos_enc") != "center+corner_latent" or not get("use_grasp_loss", False) or \
-                get("use_render_seg_loss", False):
-            raise NotImplementedError("hands_amd.HAMER: only the shipped default switches are built "
-                                      "(pos_enc='center+corner_latent', grasp head on, renderer off)")
+        # built: pos_enc 'center+corner_latent' (shipped) or None (no KPE: model.py:91-97,102-104), grasp head on or off
+        # (model.py:59-72,136-143); 'dense_latent' (dense angle maps) and the renderer are not
+        if get("pos_enc") not in ("center+corner_latent", None) or get("use_render_seg_loss", False):
+            raise NotImplementedError("hands_amd.HAMER: pos_enc must be 'center+corner_latent' or None, renderer off")
         self.n_freq = int(get("n_freq_pos_enc", 4))
         self.vit_input_size = (256, 192)
         self.backbone = ViTParams()
@@ -197,11 +197,13 @@ class HAMER(EngineSwitches, nn.Module):
         self.mano_r = MANOHead(True, focal_length, img_res, assets[0])
         self.mano_l = MANOHead(False, focal_length, img_res, assets[1])
         self.pos_enc = get("pos_enc")
-        self.kpe = _KPE(self.n_freq)
-        self.use_grasp_loss = True
-        self.grasp_classifier = nn.Sequential(
-            nn.Linear(10 + 144, 1024), nn.ReLU(inplace=True), nn.Linear(1024, 512), nn.ReLU(inplace=True),
-            nn.Linear(512, 128), nn.ReLU(inplace=True), nn.Linear(128, 9))
+        if self.pos_enc is not None:
+            self.kpe = _KPE(self.n_freq)
+        self.use_grasp_loss = bool(get("use_grasp_loss", False))
+        if self.use_grasp_loss:
+            self.grasp_classifier = nn.Sequential(
+                nn.Linear(10 + 144, 1024), nn.ReLU(inplace=True), nn.Linear(1024, 512), nn.ReLU(inplace=True),
+                nn.Linear(512, 128), nn.ReLU(inplace=True), nn.Linear(128, 9))
         self.img_res, self.focal_length = img_res, focal_length
         self._packed = None
         self._packed_dev = None
@@ -246,7 +248,9 @@ class HAMER(EngineSwitches, nn.Module):
         P = {"patch": pack_conv(cpu(vit.patch_embed.proj.weight), cpu(vit.patch_embed.proj.bias), 16, 2, dev,
                                 cin_pad_to=4),
              "pos": cpu(vit.pos_embed)[0].contiguous().to(dev),
-             "kpe0": lin(self.kpe.feat_mlp[0]), "kpe2": lin(self.kpe.feat_mlp[2]), "blocks": [], "dec": []}
+             "blocks": [], "dec": []}
+        if self.pos_enc is not None:
+            P["kpe0"], P["kpe2"] = lin(self.kpe.feat_mlp[0]), lin(self.kpe.feat_mlp[2])
         ln = lambda m: (cpu(m.weight).to(dev), cpu(m.bias).to(dev))
         for blk in vit.blocks:
             P["blocks"].append({"n1": ln(blk.norm1), "qkv": lin(blk.attn.qkv), "proj": lin(blk.attn.proj),
@@ -272,11 +276,12 @@ class HAMER(EngineSwitches, nn.Module):
         init = torch.zeros(112)
         init[:96], init[96:106], init[108:111] = cpu(mh.init_hand_pose)[0], cpu(mh.init_betas)[0], cpu(mh.init_cam)[0]
         P["init"] = init.to(dev)
-        g = self.grasp_classifier
-        gcol = [144 + i for i in range(10)] + list(range(144))          # reference cat([shape, pose])
-        P["g0"] = pack_linear(cpu(g[0].weight), cpu(g[0].bias), dev, col_index=gcol, k_total=154)
-        P["g2"], P["g4"] = lin(g[2]), lin(g[4])
-        P["g6"] = lin(g[6], n_total=12)
+        if self.use_grasp_loss:
+            g = self.grasp_classifier
+            gcol = [144 + i for i in range(10)] + list(range(144))          # reference cat([shape, pose])
+            P["g0"] = pack_linear(cpu(g[0].weight), cpu(g[0].bias), dev, col_index=gcol, k_total=154)
+            P["g2"], P["g4"] = lin(g[2]), lin(g[4])
+            P["g6"] = lin(g[6], n_total=12)
         for side, head in (("mano_r", self.mano_r), ("mano_l", self.mano_l)):
             m = pack_mano(head.mano.asset(), dev)
             m["consts"] = mano_consts(m)
@@ -332,13 +337,15 @@ class HAMER(EngineSwitches, nn.Module):
             check(L.hands_resize_crop_nchw3_to_nhwc4_f32(ptr(im), ptr(x4, side * bz * S * Wc * 4), bz, Hin, Win, S,
                                                          (S - Wc) // 2, Wc, stream), "resize_crop")
         # -- KPE embedding (pos_emb.py:28-64) -------------------------------------------------------
-        center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
-        corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0)
-        kld = P["kpe0"].Cin
-        enc, k1, kpe = buf("kpe_enc", B2 * kld), buf("kpe_h", B2 * Cd), buf("kpe", B2 * Cd)
-        check(L.hands_kpe_encode_f32(ptr(center), ptr(corner), ptr(enc), B2, kld, self.n_freq, stream), "kpe_encode")
-        hgemm(P["kpe0"], enc, B2, k1, ACT_RELU)
-        hgemm(P["kpe2"], k1, B2, kpe, ACT_RELU)
+        kpe = None
+        if self.pos_enc is not None:
+            center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
+            corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0)
+            kld = P["kpe0"].Cin
+            enc, k1, kpe = buf("kpe_enc", B2 * kld), buf("kpe_h", B2 * Cd), buf("kpe", B2 * Cd)
+            check(L.hands_kpe_encode_f32(ptr(center), ptr(corner), ptr(enc), B2, kld, self.n_freq, stream), "kpe_encode")
+            hgemm(P["kpe0"], enc, B2, k1, ACT_RELU)
+            hgemm(P["kpe2"], k1, B2, kpe, ACT_RELU)
         # -- ViT-H/16 + decoder head, per chunk of crops -----------------------------------------------
         pred = torch.empty(B2, 112, device=dev)
         inner = DEC_HEADS * DEC_HDIM
@@ -360,7 +367,7 @@ class HAMER(EngineSwitches, nn.Module):
             x = cbuf("vit_x", Mc * Cd)
             ho, wo = self.engine.conv(L, P["patch"], x4, nB, S, Wc, x, ACT_NONE, sh, x_off=lo * S * Wc * 4)
             assert (ho, wo) == (TOKENS_H, TOKENS_W)
-            check(L.hands_add_pos_f32(ptr(x), ptr(P["pos"]), ptr(kpe, lo * Cd), nB, T, Cd, sh), "add_pos")
+            check(L.hands_add_pos_f32(ptr(x), ptr(P["pos"]), ptr(kpe, lo * Cd) if kpe is not None else None, nB, T, Cd, sh), "add_pos")
             y, qkv, att, hid = cbuf("vit_y", Mc * Cd), cbuf("vit_qkv", Mc * 3 * Cd), cbuf("vit_att", Mc * Cd), cbuf("vit_h", Mc * 4 * Cd)
             for blk in P["blocks"]:
                 lnorm(x, blk["n1"], y, Mc, Cd, 1e-6)
@@ -371,7 +378,7 @@ class HAMER(EngineSwitches, nn.Module):
                 gemm(blk["fc1"], y, Mc, hid, ACT_GELU)
                 gemm(blk["fc2"], hid, Mc, x, res=x)
             feat = cbuf("vit_feat", Mc * Cd)
-            lnorm(x, P["last"], feat, Mc, Cd, 1e-6, addvec=ptr(kpe, lo * Cd), rpv=T)   # last_norm, + kpe (model.py:102-104)
+            lnorm(x, P["last"], feat, Mc, Cd, 1e-6, addvec=ptr(kpe, lo * Cd) if kpe is not None else None, rpv=T)   # last_norm, + kpe (model.py:102-104)
             # decoder head (mano_head.py:58-112)
             xd = cbuf("dec_x", nB * DEC_DIM)
             xd[: nB * DEC_DIM].view(nB, DEC_DIM).copy_(P["tok0"].expand(nB, DEC_DIM))
@@ -422,6 +429,8 @@ class HAMER(EngineSwitches, nn.Module):
         output = run_mano_heads(L, P["mano_r"], P["mano_l"], rot, shape, cam, cam, K, float(self.img_res), bz,
                                 stream, buf, self.engine)
         # -- grasp classifier (model.py:136-143) -----------------------------------------------------
+        if not self.use_grasp_loss:
+            return output
         gld = P["g0"].Cin
         gin = buf("grasp_in", B2 * gld)
         check(L.hands_grasp_input_f32(ptr(shape), 10, ptr(rot), ptr(shape), ptr(gin), B2, bz, 0, gld, stream),

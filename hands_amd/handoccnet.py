@@ -65,12 +65,15 @@ class HandOccNet(EngineSwitches, nn.Module):
         args = args if args is not None else HANDOCC_DEFAULT_ARGS
         get = args.get if hasattr(args, "get") else (lambda k, d=None: getattr(args, k, d))
         self.args = args
-        if get("pos_enc") != "center+corner_latent" or not get("use_grasp_loss", False) or \
-                get("use_render_seg_loss", False):
-            raise NotImplementedError("hands_amd.HandOccNet: only the shipped default switches are built")
+        # built: pos_enc 'center+corner_latent' (shipped) or None (model.py:74-89: no KPE anywhere), grasp head on or off
+        if get("pos_enc") not in ("center+corner_latent", None) or get("use_render_seg_loss", False):
+            raise NotImplementedError("hands_amd.HandOccNet: pos_enc must be 'center+corner_latent' or None, renderer off")
         self.n_freq = int(get("n_freq_pos_enc", 4))
         self.input_size = (256, 256)
-        build_tree(self, load_manifest("handoccnet_light"))
+        self.pos_enc = get("pos_enc")
+        self.use_grasp_loss = bool(get("use_grasp_loss", False))
+        skip = (("kpe.",) if self.pos_enc is None else ()) + (("grasp_classifier.",) if not self.use_grasp_loss else ())
+        build_tree(self, load_manifest("handoccnet_light"), skip_prefixes=skip)
         assets = mano_assets or (None, None)
         self.mano_r = MANOHead(True, focal_length, img_res, assets[0])
         self.mano_l = MANOHead(False, focal_length, img_res, assets[1])
@@ -79,8 +82,6 @@ class HandOccNet(EngineSwitches, nn.Module):
         vv, uu = torch.meshgrid(rng, rng, indexing="ij")
         self.regressor.hand_regHead.uu.copy_((uu + 0.5) / 32)
         self.regressor.hand_regHead.vv.copy_((vv + 0.5) / 32)
-        self.pos_enc = get("pos_enc")
-        self.use_grasp_loss = True
         self.img_res, self.focal_length = img_res, focal_length
         self._packed = None
         self._packed_dev = None
@@ -171,7 +172,8 @@ class HandOccNet(EngineSwitches, nn.Module):
         P["smooth3"] = conv("backbone.smooth3", 1, 1)
         P["gate"] = conv("backbone.attention_module.spatial.conv", 1, 3, bn="backbone.attention_module.spatial.bn",
                          cin_pad_to=4)
-        P["kpe0"], P["kpe2"] = lin("kpe.feat_mlp.0"), lin("kpe.feat_mlp.2")
+        if self.pos_enc is not None:
+            P["kpe0"], P["kpe2"] = lin("kpe.feat_mlp.0"), lin("kpe.feat_mlp.2")
         for T, inj in (("FIT", True), ("SET", False)):
             layers = []
             for i in range(2):
@@ -215,10 +217,11 @@ class HandOccNet(EngineSwitches, nn.Module):
         bd = torch.cat([sd[mp + ".pose_reg.bias"], sd[mp + ".shape_reg.bias"], sd[mp + ".cam_reg.bias"]], 0)
         rows = list(range(96)) + [96 + i for i in range(10)] + [108 + i for i in range(3)]
         P["regs"] = pack_linear(wd, bd, dev, row_index=rows, n_total=112)
-        gcol = [144 + i for i in range(10)] + list(range(144))
-        P["g0"] = lin("grasp_classifier.0", col_index=gcol, k_total=154)
-        P["g2"], P["g4"] = lin("grasp_classifier.2"), lin("grasp_classifier.4")
-        P["g6"] = lin("grasp_classifier.6", n_total=12)
+        if self.use_grasp_loss:
+            gcol = [144 + i for i in range(10)] + list(range(144))
+            P["g0"] = lin("grasp_classifier.0", col_index=gcol, k_total=154)
+            P["g2"], P["g4"] = lin("grasp_classifier.2"), lin("grasp_classifier.4")
+            P["g6"] = lin("grasp_classifier.6", n_total=12)
         for side, head in (("mano_r", self.mano_r), ("mano_l", self.mano_l)):
             m = pack_mano(head.mano.asset(), dev)
             m["consts"] = mano_consts(m)
@@ -256,8 +259,11 @@ class HandOccNet(EngineSwitches, nn.Module):
             check(L.hands_resize_crop_nchw3_to_nhwc4_f32(ptr(im), ptr(x4, side * bz * S * S * 4), bz, Hin, Win, S, 0, S,
                                                          main.cuda_stream), "resize")
         # KPE angles (hamer_light/pos_emb.py:28-64, feat_dim 256): private copies
-        center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
-        corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0)
+        if self.pos_enc is not None:
+            center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
+            corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0)
+        else:
+            center = corner = torch.zeros(B2, 8, dtype=torch.float32, device=dev)      # unused
         dbg = self.__dict__.get("_debug")
         capturing = self.engine._capturing(L, main.cuda_stream)
         pipelined = bool(self.async_forward and self.engine.overlap and dbg is None and self.engine.hook is None and not capturing)
@@ -298,11 +304,15 @@ class HandOccNet(EngineSwitches, nn.Module):
             independent, so the 2*bz crops may be cut into chunks that run on separate HIP streams."""
             npix = B2 * NTOK
             conv, hconv = _conv_fns(L, stream, new, self.engine, self.small_map_splitk)
-            enc = new(B2, P["kpe0"].Cin)
-            check(L.hands_kpe_encode_f32(ptr(center), ptr(corner), ptr(enc), B2, P["kpe0"].Cin, self.n_freq, stream), "kpe")
-            k1, _, _ = conv(P["kpe0"], enc, B2, 1, 1, ACT_RELU)
-            kpe, _, _ = conv(P["kpe2"], k1, B2, 1, 1, ACT_RELU)
-            kpe = kpe.view(B2, CF)
+            if self.pos_enc is not None:
+                enc = new(B2, P["kpe0"].Cin)
+                check(L.hands_kpe_encode_f32(ptr(center), ptr(corner), ptr(enc), B2, P["kpe0"].Cin, self.n_freq, stream), "kpe")
+                k1, _, _ = conv(P["kpe0"], enc, B2, 1, 1, ACT_RELU)
+                kpe, _, _ = conv(P["kpe2"], k1, B2, 1, 1, ACT_RELU)
+                kpe = kpe.view(B2, CF)
+            else:
+                # pos_enc None (model.py:74-89: no KPE term anywhere): a zero vector through the same kernels -- x + 0 == x
+                kpe = torch.zeros(B2, CF, dtype=torch.float32, device=dev)
             # -- LeakyReLU ResNet-50 (backbone.py:44-53) ------------------------------------------------
             H, W = (S - 1) // 2 + 1, (S - 1) // 2 + 1
             Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
@@ -490,6 +500,8 @@ class HandOccNet(EngineSwitches, nn.Module):
             return ws[name]
 
         output = run_mano_heads(L, P["mano_r"], P["mano_l"], rot, shape, cam, cam, K, float(self.img_res), bz, stream, buf, self.engine)
+        if not self.use_grasp_loss:
+            return output
         gld = P["g0"].Cin
         gin = new(B2, gld)
         check(L.hands_grasp_input_f32(ptr(shape), 10, ptr(rot), ptr(shape), ptr(gin), B2, bz, 0, gld, stream), "grasp_in")

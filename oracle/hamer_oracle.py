@@ -52,7 +52,8 @@ def vit_forward(x_img, kpe_emb, sd, p="backbone", depth=VIT_DEPTH, return_blocks
     x = x.flatten(2).transpose(1, 2)
     pos = sd[p + ".pos_embed"]
     x = x + pos[:, 1:] + pos[:, :1]
-    x = x + kpe_emb[:, None, :]
+    if kpe_emb is not None:                      # vit.py:329-330: only with a KPE embedding (model.py:91-97)
+        x = x + kpe_emb[:, None, :]
     probes = []
     for i in range(depth):
         b = f"{p}.blocks.{i}"
@@ -118,13 +119,15 @@ def preprocess(inputs):
 
 @torch.no_grad()
 def hamer_forward(sd, asset_r, asset_l, inputs, meta_info, img_res=224, n_freq=4, vit_depth=VIT_DEPTH,
-                  return_intermediates=False):
+                  return_intermediates=False, pos_enc="center+corner_latent", use_grasp_loss=True):
     K = meta_info["intrinsics"]
     bz = inputs["r_img"].shape[0]
     x = preprocess(inputs)
-    kpe = torch.cat([kpe_embedding(inputs, "r_", sd, n_freq), kpe_embedding(inputs, "l_", sd, n_freq)], 0)
+    kpe = None
+    if pos_enc is not None:                                                      # model.py:91-97
+        kpe = torch.cat([kpe_embedding(inputs, "r_", sd, n_freq), kpe_embedding(inputs, "l_", sd, n_freq)], 0)
     tokens, blocks = vit_forward(x, kpe, sd, depth=vit_depth, return_blocks=True)
-    feats = tokens + kpe[:, None, :]                                             # model.py:102-104
+    feats = tokens + kpe[:, None, :] if kpe is not None else tokens             # model.py:102-104
     pose6d, betas, cam, tok = decoder_forward(feats, sd)
     rotmat = rot6d_to_rotmat_columns(pose6d).view(2 * bz, 16, 3, 3)
     out = {}
@@ -141,8 +144,9 @@ def hamer_forward(sd, asset_r, asset_l, inputs, meta_info, img_res=224, n_freq=4
             g = F.relu(_lin(g, sd, f"grasp_classifier.{i}"))
         return _lin(g, sd, "grasp_classifier.6")
 
-    out["grasp.r"] = grasp(betas[:bz], rotmat[:bz])
-    out["grasp.l"] = grasp(betas[bz:], rotmat[bz:])
+    if use_grasp_loss:                                                           # model.py:136-143
+        out["grasp.r"] = grasp(betas[:bz], rotmat[:bz])
+        out["grasp.l"] = grasp(betas[bz:], rotmat[bz:])
     if return_intermediates:
         return out, {"x": x, "kpe": kpe, "tokens": tokens, "blocks": blocks, "pose6d": pose6d,
                      "betas": betas, "cam": cam, "token_out": tok}

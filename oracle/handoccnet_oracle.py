@@ -171,13 +171,17 @@ def kpe_embedding(inputs, prefix, sd, n_freq=4):
 
 
 @torch.no_grad()
-def handoccnet_forward(sd, asset_r, asset_l, inputs, meta_info, img_res=224, n_freq=4, return_intermediates=False):
+def handoccnet_forward(sd, asset_r, asset_l, inputs, meta_info, img_res=224, n_freq=4, return_intermediates=False,
+                       pos_enc="center+corner_latent", use_grasp_loss=True):
     K = meta_info["intrinsics"]
     bz = inputs["r_img"].shape[0]
     r = F.interpolate(inputs["r_img"], size=256, mode="bilinear", align_corners=False)
     l = F.interpolate(inputs["l_img"], size=256, mode="bilinear", align_corners=False)
     x = torch.cat([r, l], dim=0)
-    kpe = torch.cat([kpe_embedding(inputs, "r_", sd, n_freq), kpe_embedding(inputs, "l_", sd, n_freq)], 0)
+    if pos_enc is not None:
+        kpe = torch.cat([kpe_embedding(inputs, "r_", sd, n_freq), kpe_embedding(inputs, "l_", sd, n_freq)], 0)
+    else:                                                # model.py:74-89: no KPE term anywhere (x + 0 == x)
+        kpe = torch.zeros(x.shape[0], 256, dtype=x.dtype)
     kpe_map = kpe[:, :, None, None]                      # constant over the 32x32 map (pos_emb.py:44)
     primary, secondary, inter = fpn(x, sd)
     probes = {}
@@ -203,6 +207,7 @@ def handoccnet_forward(sd, asset_r, asset_l, inputs, meta_info, img_res=224, n_f
             g = F.relu(_lin(g, sd, f"grasp_classifier.{i}"))
         return _lin(g, sd, "grasp_classifier.6")
 
-    out["grasp.r"] = grasp(shape[:bz], rot[:bz])
-    out["grasp.l"] = grasp(shape[bz:], rot[bz:])
+    if use_grasp_loss:                                   # model.py:113-120
+        out["grasp.r"] = grasp(shape[:bz], rot[:bz])
+        out["grasp.l"] = grasp(shape[bz:], rot[bz:])
     return (out, inter) if return_intermediates else out

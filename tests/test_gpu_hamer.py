@@ -200,3 +200,27 @@ def test_graphed_hamer_is_bit_identical(hamer_gpu):
             assert torch.equal(got[k], ref[k]), k
     with pytest.raises(ValueError):           # persistent workspaces: one captured instance at a time
         GraphedForward(hamer_gpu, *samples[0], depth=2)
+
+
+@pytest.mark.parametrize("name", ["hamer_light", "handoccnet_light"])
+def test_no_kpe_no_grasp_switches_vs_reference_fixture(golden_dir, name):
+    """pos_enc=None + use_grasp_loss=False through the HIP path of HAMER and HandOccNet against what the reference produced
+    (tests/golden/make_golden_switches_other.py): 20 keys, vertices within 1e-6 m."""
+    import json
+    d = np.load(os.path.join(golden_dir, f"{name}_switch_nokpe.npz"))
+    meta = json.loads(str(d["meta"]))
+    base = hands_amd.HAMER_DEFAULT_ARGS if name == "hamer_light" else hands_amd.HANDOCC_DEFAULT_ARGS
+    args = type(base)(dict(base, **meta["config"]))
+    model = hands_amd.apply_recipe(hands_amd.HAMER(args) if name == "hamer_light" else hands_amd.HandOccNet(args=args)).eval().to(DEV)
+    inputs, meta_info = synthetic_inputs(meta["bz"], meta["seed"], device=DEV)
+    out = model(inputs, meta_info)
+    torch.cuda.synchronize()
+    keys = [k[4:] for k in d.files if k.startswith("out/")]
+    assert sorted(out.keys()) == sorted(keys) and len(keys) == 20
+    for k in keys:
+        tol = 2e-4
+        np.testing.assert_allclose(out[k].cpu().numpy(), d["out/" + k], rtol=tol, atol=tol, err_msg=k)
+    for hn in "rl":
+        verr = np.abs(out[f"mano.vertices.{hn}"].cpu().numpy() - d[f"out/mano.vertices.{hn}"]).max()
+        mp = O.mpjpe_ra_mm(out[f"mano.joints3d.{hn}"].cpu(), torch.from_numpy(d[f"out/mano.joints3d.{hn}"]))
+        assert verr < 1e-6 and mp < 1e-3, (name, hn, verr, mp)

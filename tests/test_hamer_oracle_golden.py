@@ -69,3 +69,29 @@ def test_rot6d_columns_is_transpose_of_rows():
     g = torch.Generator().manual_seed(0)
     d6 = torch.randn(32, 6, generator=g)
     assert torch.allclose(H.rot6d_to_rotmat_columns(d6), O.rotation_6d_to_matrix(d6).transpose(1, 2), atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["hamer_light", "handoccnet_light"])
+def test_no_kpe_no_grasp_switches_match_reference(golden_dir, name):
+    """pos_enc=None (no KPE term anywhere) and use_grasp_loss=False for HAMER (hamer_light/model.py:53-72,91-104,136-143) and
+    HandOccNet (handoccnet_light/model.py:74-89,113-120): the host mirror drops the `kpe.*` / `grasp_classifier.*` tensors like
+    the reference and the oracle reproduces the reference's 20 outputs (tests/golden/make_golden_switches_other.py)."""
+    import hands_amd
+    from oracle import handoccnet_oracle as HO
+    d = np.load(os.path.join(golden_dir, f"{name}_switch_nokpe.npz"))
+    meta = json.loads(str(d["meta"]))
+    base = hands_amd.HAMER_DEFAULT_ARGS if name == "hamer_light" else hands_amd.HANDOCC_DEFAULT_ARGS
+    args = type(base)(dict(base, **meta["config"]))
+    model = hands_amd.apply_recipe(hands_amd.HAMER(args) if name == "hamer_light" else hands_amd.HandOccNet(args=args)).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    assert sum(1 for k in sd if ".mano." not in k) == meta["n_state_dict"]
+    assert not any(k.startswith(("kpe.", "grasp_classifier.")) for k in sd)
+    inputs, meta_info = synthetic_inputs(meta["bz"], meta["seed"])
+    fwd = H.hamer_forward if name == "hamer_light" else HO.handoccnet_forward
+    out = fwd(sd, synthetic_mano_asset(True), synthetic_mano_asset(False), inputs, meta_info, pos_enc=None, use_grasp_loss=False)
+    keys = sorted(k[4:] for k in d.files if k.startswith("out/"))
+    assert sorted(out.keys()) == keys and len(keys) == 20
+    for k in keys:
+        np.testing.assert_allclose(out[k].numpy(), d["out/" + k], rtol=5e-5, atol=5e-5, err_msg=k)
+    for hn in "rl":
+        assert np.abs(out[f"mano.vertices.{hn}"].numpy() - d[f"out/mano.vertices.{hn}"]).max() < 1e-5
