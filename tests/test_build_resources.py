@@ -21,6 +21,12 @@ def test_hot_kernels_do_not_spill(tmp_path, src):
                        (["-fno-slp-vectorize"] if src == "conv_wino.hip" else []),      # as hands_amd/csrc/Makefile builds it
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
+    if src == "mano_lbs.hip":
+        # the fused MANO kernel must keep FOUR workgroups per CU (<= 128 registers, <= 40 KB of LDS): tools/prof_mano.py measured
+        # a second dispatch round 25 us late when an instrumented copy needed 130
+        b = next(b for b in re.split(r"Function Name: ", p.stderr)[1:] if "mano_heads_kernelILb0" in b.split()[0])
+        vg, lds = int(re.search(r"VGPRs: (\d+)", b).group(1)), int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1))
+        assert vg <= 128 and lds <= 40960, (vg, lds)
     if src == "conv_wino.hip":      # three workgroups per CU: <= 168 registers, <= 53 KB of LDS, accumulators never copied to AGPRs
         for b in re.split(r"Function Name: ", p.stderr)[1:]:
             vg, ag = int(re.search(r"VGPRs: (\d+)", b).group(1)), int(re.search(r"AGPRs: (\d+)", b).group(1))
@@ -59,3 +65,27 @@ def test_fp32_conv_kernels_keep_four_workgroups_per_cu(tmp_path):
         assert vgprs + agprs <= 128 and lds <= 40960, (name, vgprs, agprs, lds)
         seen += 1
     assert seen == 6
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_vit_attention_fits_two_workgroups_per_cu(tmp_path):
+    """attention_kernel<12, 80> (csrc/transformer.hip): 12 waves per workgroup (a multiple of the 4 SIMDs: three each), <= 80
+    registers (six waves per SIMD) and <= 80 KB of dynamic LDS, i.e. TWO workgroups per CU, no scratch beyond a handful of
+    spilled registers.  The 6-wave / 168-register form of rounds 1-3 fitted one workgroup per CU with a 2-2-1-1 SIMD load
+    (tools/prof_attn.py) and ran 35 % slower."""
+    src = os.path.join(ROOT, "hands_amd", "csrc", "transformer.hip")
+    p = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{ROOT}/hands_amd/csrc",
+                        "-fno-fast-math", "-ffp-contract=off", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o",
+                        str(tmp_path / "o.o")], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    b = next(b for b in re.split(r"Function Name: ", p.stderr)[1:] if "attention_kernelILi12ELi80" in b.split()[0])
+    vg = int(re.search(r"VGPRs: (\d+)", b).group(1))
+    spill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
+    occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
+    assert vg <= 80 and occ >= 6 and spill <= 16, (vg, occ, spill)
+    text = open(src).read()
+    assert "dim3(768)" in text and "attention_kernel<12, 80>" in text          # 12 waves
+    m = re.search(r"constexpr int attention_lds_bytes\(\) \{\s*return 4 \* \((.*?)\);", text, re.S)
+    assert m, "attention_lds_bytes() not found"
+    TW, D = 12, 80
+    assert 2 * 4 * max(16 * TW * (D + 4), D * (16 * TW + 4)) <= 160 * 1024       # two workgroups' LDS fit a CU
