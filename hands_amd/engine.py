@@ -41,11 +41,6 @@ class ConvEngine:
         self.fuse_mano = True         # MANOHead.forward of both hands as one launch (hands_mano_heads_f32)
         self.fuse_pre = True          # handoccnet_light's pre-activation units: BatchNorm -> LeakyReLU folded into the operand
                                       # staging of the unit's first (pointwise) convolution (hands_conv2d_nhwc_pre_f32)
-        self.chain_limit = 0          # > 0: every launch whose contraction is longer than 2 x chain_limit floats is cut into
-                                      # S = Kpad / chain_limit K-slices (deterministic split-K: the slices' partial sums are
-                                      # added in slice order), i.e. no fp32 accumulation chain is longer than chain_limit --
-                                      # blocked summation, fewer roundings per output.  Costs a workspace round trip per such
-                                      # launch; used by HandOccNet (DESIGN.md "Conditioning note"), 0 elsewhere
         self.hook = None              # callable(phase, pc, npix, stream_handle, has_res, kernel): bench.py brackets
                                       # every MFMA launch (conv_igemm and the fused stem) with events; `kernel` is the
                                       # kernel the launch really runs (conv_igemm_f32_kernel / conv_igemm_sk_f32_kernel =
@@ -57,7 +52,7 @@ class ConvEngine:
 
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
-        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "winograd", "fuse_mano", "fuse_pre", "stream_k", "math", "chain_limit"):
+        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "winograd", "fuse_mano", "fuse_pre", "stream_k", "math"):
             setattr(e, k, getattr(self, k))
         return e
 
@@ -129,9 +124,6 @@ class ConvEngine:
             if hook is not None:
                 hook("end", pc, B * Ho * Wo, stream, False, "conv_wino_f32_kernel")
             return Ho, Wo
-        if self.chain_limit and pc.Kpad >= 2 * self.chain_limit and self.use_splitk and self.math == "fp32":
-            # (not the Winograd launches above: their chains are Cin long)
-            S = max(S, min(pc.Kpad // self.chain_limit, 32))
         if pre is not None:
             # pointwise layer behind an eval BatchNorm -> LeakyReLU (pre = (scale, shift) device vectors): the affine +
             # activation is applied to the operand on its way into LDS (hands_conv2d_nhwc_pre_f32)

@@ -76,3 +76,23 @@ def test_handoccnet_default_scope_multi_seed_parity(golden_dir):
         verr = max(np.abs(out[f"mano.vertices.{h}"].cpu().numpy() - d[f"out/mano.vertices.{h}"]).max() for h in "rl")
         print(f"handoccnet_light golden seed {seed}: max vertex err vs the reference's own output {verr:.3e} m")
         assert verr <= BAR_M, (seed, verr)
+
+
+def test_handoccnet_error_distribution_guard():
+    """48 more input seeds (200-247) through the shipped default route: median <= 6.5e-7 m, 90th percentile <= 9e-7 m, at most
+    3 inputs above 1e-6 m and none above 1.6e-6 m -- the distribution measured in round 4 (median 5.7e-7, p90 7.8e-7, 2.1 % above
+    1e-6 with a maximum of 1.5e-6 over 288 seeds), with headroom for one more tail event."""
+    model = hands_amd.apply_recipe(hands_amd.HandOccNet())
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).eval()
+    ar, al = hands_amd.synthetic_mano_asset(True), hands_amd.synthetic_mano_asset(False)
+    errs = []
+    for seed in range(200, 248):
+        ci, cm = synthetic_inputs(2, seed)
+        ref = HO.handoccnet_forward(sd, ar, al, ci, cm)
+        out = model({k: v.to(DEV) for k, v in ci.items()}, {k: v.to(DEV) for k, v in cm.items()})
+        torch.cuda.synchronize()
+        errs.append(max((out[f"mano.vertices.{h}"].cpu() - ref[f"mano.vertices.{h}"]).abs().max().item() for h in "rl"))
+    e = np.sort(np.array(errs))
+    print(f"handoccnet_light, 48 seeds: median {np.median(e):.3e}, p90 {np.percentile(e, 90):.3e}, max {e[-1]:.3e}, above 1e-6: {(e > 1e-6).sum()}")
+    assert np.median(e) <= 6.5e-7 and np.percentile(e, 90) <= 9e-7 and (e > 1e-6).sum() <= 3 and e[-1] <= 1.6e-6, e[-6:]

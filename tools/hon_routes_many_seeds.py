@@ -1,3 +1,6 @@
+"""HandOccNet: max vertex error against the oracle per 3x3 route (direct / Winograd in the trunk / backbone / every layer) over many input
+seeds, and the reference's own fp32-vs-fp64 error on the seeds above 9e-7 (dev tool, GPU box).
+usage: python tools/hon_routes_many_seeds.py [first seed] [last seed + 1]   (the blocked-summation variants of round 4 need commit 6b4a330)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); os.environ.setdefault("HANDS_SYNTHETIC_MANO", "1")
 import numpy as np, torch, hands_amd
@@ -9,15 +12,14 @@ m = hands_amd.apply_recipe(hands_amd.HandOccNet()); sd = {k: v.clone() for k, v 
 sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
 m = m.to("cuda").eval(); m.async_forward = False
 c64 = lambda d: {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}
-res = {"backbone": [], "all+chain512": [], "all+chain256": [], "backbone+chain512": [], "backbone+chain256": []}
+res = {"direct": [], "trunk": [], "backbone": [], "all": []}
 seeds = list(range(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 196))
 for seed in seeds:
     ci, cm = synthetic_inputs(2, seed)
     ref = HO.handoccnet_forward(sd, ar, al, ci, cm)
     for route in res:
         m.engine.winograd = route != "direct"
-        m.engine.chain_limit = int(route.split("chain")[1]) if "chain" in route else 0
-        sc = route.split("+")[0] if route != "direct" else "backbone"
+        sc = route if route != "direct" else "backbone"
         if m.winograd_scope != sc:
             m.winograd_scope = sc
         m.invalidate_packed()
