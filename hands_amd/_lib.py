@@ -73,6 +73,12 @@ SIGNATURES = {
     "hands_sumpool_nhwc_f32": [_P, _P, _I, _I, _I, _I, _P],
     "hands_avgpool_nhwc_f32": [_P, _P, _I, _I, _I, _I, _P],
     "hands_image_posenc_nhwc_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hands_frontend_dense_maps_f32": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "hands_dense_posenc_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "hands_concat_nhwc_f32": [_P, _I, _I, _P, _I, _P, C.c_longlong, _I, _P, _I, _I, _I, _I, _P],
+    "hands_upsample_bilinear_ac_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hands_rot_leftmul_f32": [_P, _P, _I, _P],
+    "hands_perspective_correction_f32": [_P, _P, _P, _P, _I, _P],
     "hands_kpe_concat_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "hands_hmr_init_f32": [_P, _P, _I, _I, _I, _P],
     "hands_rot6d_to_matrix_f32": [_P, _I, _P, _I, _P],
@@ -119,7 +125,7 @@ SIGNATURES = {
 EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string", "hands_conv2d_workspace_floats", "hands_pack_conv3x3_winograd_floats", "hands_conv3x3_winograd_executed_macs",
                  "hands_conv2d_streamk_workspace_bytes", "hands_stream_is_capturing")
 
-ABI_VERSION = 2      # HANDS_ABI_VERSION of include/hands_hip.h this wrapper was written against
+ABI_VERSION = 3      # HANDS_ABI_VERSION of include/hands_hip.h this wrapper was written against
 _lib = None
 
 

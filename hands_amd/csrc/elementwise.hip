@@ -154,6 +154,178 @@ __global__ void image_posenc_kernel(const float* __restrict__ img, const float* 
   }
 }
 
+
+// ---- per-pixel ("dense") positional encodings: pos_enc = 'dense' | 'dense_latent' | 'cam_conv' ------------------------------
+// (model.py:462-481).  Source value of encoding channel ch at pixel `pix` of one sample: L > 0: sin / cos(2^k angle[ci]) with
+// ch = (k Ca + ci) 2 + {sin, cos} (torch.cat([sin, cos], dim=3).reshape(bz, -1, w, h) of the (bz, L, c, w, h) products), L == 0:
+// the raw map ('cam_conv'); both times the crop mask.
+__device__ __forceinline__ float dense_src(const float* __restrict__ ang, const float* __restrict__ msk, int Ca, int HsWs,
+                                           int pix, int L, int ch) {
+  const float m = msk[pix];
+  if (L == 0) return ang[(long long)ch * HsWs + pix] * m;
+  const int sc = ch & 1, q = ch >> 1, ci = q % Ca, k = q / Ca;
+  const float x = (float)(1 << k) * ang[(long long)ci * HsWs + pix];
+  return (sc ? cosf(x) : sinf(x)) * m;
+}
+
+// F.interpolate(mode='bilinear', align_corners=True) tap of output index `dst` (ATen compute_source_index_and_lambda:
+// equal sizes copy; otherwise src = dst (in - 1) / (out - 1), index truncated, lambda clamped to [0, 1]).
+struct AcTap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ AcTap ac_tap(int dst, int in, int out) {
+  AcTap t;
+  if (in == out) { t.i0 = t.i1 = dst; t.l0 = 1.f; t.l1 = 0.f; return t; }
+  const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  const float src = scale * (float)dst;
+  int i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  const float l1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+  t.i0 = i0; t.i1 = i0 + (i0 < in - 1 ? 1 : 0); t.l1 = l1; t.l0 = 1.f - l1;
+  return t;
+}
+
+// the encoding resized to (R, R) at pixel (y, x): first interpolation of model.py:471 / 480
+__device__ __forceinline__ float dense_stage1(const float* __restrict__ ang, const float* __restrict__ msk, int Ca, int Hs, int Ws,
+                                              int L, int ch, int R, int y, int x) {
+  const AcTap ty = ac_tap(y, Hs, R), tx = ac_tap(x, Ws, R);
+  const int HsWs = Hs * Ws;
+  float top = tx.l0 * dense_src(ang, msk, Ca, HsWs, ty.i0 * Ws + tx.i0, L, ch);
+  if (tx.l1 != 0.f) top += tx.l1 * dense_src(ang, msk, Ca, HsWs, ty.i0 * Ws + tx.i1, L, ch);
+  if (ty.l1 == 0.f) return ty.l0 * top;
+  float bot = tx.l0 * dense_src(ang, msk, Ca, HsWs, ty.i1 * Ws + tx.i0, L, ch);
+  if (tx.l1 != 0.f) bot += tx.l1 * dense_src(ang, msk, Ca, HsWs, ty.i1 * Ws + tx.i1, L, ch);
+  return ty.l0 * top + ty.l1 * bot;
+}
+
+// out (B, Ho, Wo, ld) NHWC: channels [c_off, c_off + Cenc) = the encoding resized to (R, R) and then to (Ho, Wo).  With `img`
+// (B, 3, Ho, Wo) NCHW the kernel writes the whole pixel: [r g b | encoding | zeros] (c_off = 3, the widened conv1's input).
+__global__ void dense_posenc_kernel(const float* __restrict__ angle, const float* __restrict__ mask, const float* __restrict__ img,
+                                    float* __restrict__ out, int B, int Ca, int Hs, int Ws, int L, int R, int Ho, int Wo, int ld,
+                                    int c_off, int Cenc) {
+  const int ncol = img ? ld : Cenc;
+  const long long total = (long long)B * Ho * Wo * ncol;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ncol);
+    const long long pix = i / ncol;
+    const int x = (int)(pix % Wo);
+    const int y = (int)((pix / Wo) % Ho);
+    const int b = (int)(pix / ((long long)Wo * Ho));
+    const int ch = img ? c - c_off : c;
+    float v;
+    if (img && c < 3) {
+      v = img[(((long long)b * 3 + c) * Ho + y) * Wo + x];
+    } else if (ch >= Cenc) {
+      v = 0.f;
+    } else {
+      const float* ang = angle + (long long)b * Ca * Hs * Ws;
+      const float* msk = mask + (long long)b * Hs * Ws;
+      if (Ho == R && Wo == R) {
+        v = dense_stage1(ang, msk, Ca, Hs, Ws, L, ch, R, y, x);
+      } else {                                   // second interpolation (model.py:248-249 / 280-281)
+        const AcTap ty = ac_tap(y, R, Ho), tx = ac_tap(x, R, Wo);
+        float top = tx.l0 * dense_stage1(ang, msk, Ca, Hs, Ws, L, ch, R, ty.i0, tx.i0);
+        if (tx.l1 != 0.f) top += tx.l1 * dense_stage1(ang, msk, Ca, Hs, Ws, L, ch, R, ty.i0, tx.i1);
+        v = ty.l0 * top;
+        if (ty.l1 != 0.f) {
+          float bot = tx.l0 * dense_stage1(ang, msk, Ca, Hs, Ws, L, ch, R, ty.i1, tx.i0);
+          if (tx.l1 != 0.f) bot += tx.l1 * dense_stage1(ang, msk, Ca, Hs, Ws, L, ch, R, ty.i1, tx.i1);
+          v += ty.l1 * bot;
+        }
+      }
+    }
+    out[pix * ld + (img ? c : c_off + c)] = v;
+  }
+}
+
+// out[b, p, :] = [a[b, p, :Ca] (+ add[b % Bg, p, :Ca]) | extra[(b, ) p, :Cb] | zeros up to ld]: torch.cat along the channels of an
+// NHWC map (model.py:252-256, 284-288: features (+ global features) with the resized maps; :183: the depth head's grid)
+__global__ void concat_nhwc_kernel(const float* __restrict__ a, int lda, int Ca, const float* __restrict__ add, int ld_add,
+                                   const float* __restrict__ extra, long long extra_bs, int Cb, float* __restrict__ out, int ld,
+                                   int B, int Bg, int HW) {
+  const long long total = (long long)B * HW * ld;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ld);
+    const long long pix = i / ld;
+    const int b = (int)(pix / HW);
+    const int p = (int)(pix - (long long)b * HW);
+    float v = 0.f;
+    if (c < Ca) {
+      v = a[pix * lda + c];
+      if (add) v += add[((long long)(b % Bg) * HW + p) * ld_add + c];
+    } else if (c < Ca + Cb) {
+      v = extra[(long long)b * extra_bs + (long long)p * Cb + (c - Ca)];
+    }
+    out[i] = v;
+  }
+}
+
+// F.interpolate / nn.Upsample(mode='bilinear', align_corners=True) of an NHWC map (model.py:141, 146, 151)
+__global__ void upsample_bilinear_ac_kernel(const float4* __restrict__ in, float4* __restrict__ out, int B, int h, int w, int H,
+                                            int W, int C4) {
+  const long long total = (long long)B * H * W * C4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    const long long pix = i / C4;
+    const int X = (int)(pix % W);
+    const int Y = (int)((pix / W) % H);
+    const int b = (int)(pix / ((long long)W * H));
+    const AcTap ty = ac_tap(Y, h, H), tx = ac_tap(X, w, W);
+    const float4* src = in + (long long)b * h * w * C4 + c;
+    const float4 v00 = src[((long long)ty.i0 * w + tx.i0) * C4], v01 = src[((long long)ty.i0 * w + tx.i1) * C4];
+    const float4 v10 = src[((long long)ty.i1 * w + tx.i0) * C4], v11 = src[((long long)ty.i1 * w + tx.i1) * C4];
+    float4 r;
+    r.x = ty.l0 * (tx.l0 * v00.x + tx.l1 * v01.x) + ty.l1 * (tx.l0 * v10.x + tx.l1 * v11.x);
+    r.y = ty.l0 * (tx.l0 * v00.y + tx.l1 * v01.y) + ty.l1 * (tx.l0 * v10.y + tx.l1 * v11.y);
+    r.z = ty.l0 * (tx.l0 * v00.z + tx.l1 * v01.z) + ty.l1 * (tx.l0 * v10.z + tx.l1 * v11.z);
+    r.w = ty.l0 * (tx.l0 * v00.w + tx.l1 * v01.w) + ty.l1 * (tx.l0 * v10.w + tx.l1 * v11.w);
+    out[i] = r;
+  }
+}
+
+// ---- corrections of the global rotation (joint 0) -------------------------------------------------------------------------
+__device__ __forceinline__ void mat3_mul(const float* a, const float* b, float* o) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[r * 3 + c] = a[r * 3] * b[c] + a[r * 3 + 1] * b[3 + c] + a[r * 3 + 2] * b[6 + c];
+}
+
+// pos_enc = 'pcl' (model.py:330-334): pose[b, 0] = rot[b] @ pose[b, 0], in place on the heads' output (before the flip swap)
+__global__ void rot_leftmul_kernel(float* __restrict__ rotmat, const float* __restrict__ rot, int B) {
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+    float m[9], r[9], o[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { m[e] = rotmat[(long long)b * 144 + e]; r[e] = rot[(long long)b * 9 + e]; }
+    mat3_mul(r, m, o);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) rotmat[(long long)b * 144 + e] = o[e];
+  }
+}
+
+// pos_enc = 'perspective_correction' (model.py:370-376, after the flip swap): pose[b, 0] = euler_xyz(-center[b, 0], -center[b, 1], 0)
+// @ pose[b, 0] on the swapped rotations `rot_m`.  The reference does it IN PLACE: in a batch without a flipped sample `pose_r` is the
+// heads' own output tensor, which the grasp head reads afterwards -- then (and only then) the corrected matrix also goes to `rotmat`.
+__global__ void persp_correct_kernel(float* __restrict__ rot_m, float* __restrict__ rotmat, const float* __restrict__ center,
+                                     const long long* __restrict__ flipped, int Bg) {
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < 2 * Bg; b += gridDim.x * blockDim.x) {
+    bool any = false;
+    for (int s = 0; s < Bg; ++s) any |= flipped[s] != 0;
+    const float e0 = -center[b * 2], e1 = -center[b * 2 + 1];
+    const float c0 = cosf(e0), s0 = sinf(e0), c1 = cosf(e1), s1 = sinf(e1);
+    const float rx[9] = {1.f, 0.f, 0.f, 0.f, c0, -s0, 0.f, s0, c0};
+    const float ry[9] = {c1, 0.f, s1, 0.f, 1.f, 0.f, -s1, 0.f, c1};
+    float rxy[9], m[9], o[9];
+    mat3_mul(rx, ry, rxy);                       // (Rx Ry) Rz with Rz = identity (third angle is zero)
+#pragma unroll
+    for (int e = 0; e < 9; ++e) m[e] = rot_m[(long long)b * 144 + e];
+    mat3_mul(rxy, m, o);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+      rot_m[(long long)b * 144 + e] = o[e];
+      if (!any) rotmat[(long long)b * 144 + e] = o[e];
+    }
+  }
+}
+
 // ---- HMR state init --------------------------------------------------------------------------------
 // row layout (ld = F + 112): [feat F | pose6d 96 | shape 10 | 0 0 | cam 3 | 0]
 __global__ void hmr_init_kernel(float* __restrict__ state, const float* __restrict__ cam_init, int B,
@@ -303,6 +475,53 @@ int hands_image_posenc_nhwc_f32(const float* img_nchw, const float* center_angle
   const long long n = (long long)B * H * W * (Cpad / 4);
   hipLaunchKernelGGL(image_posenc_kernel, dim3(hands_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, img_nchw,
                      center_angle, corner_angle, (float4*)out, B, H * W, n_freq, mode, Cpad / 4);
+  HANDS_LAUNCH_CHECK();
+}
+
+
+int hands_dense_posenc_f32(const float* angle, const float* mask, const float* img_nchw, float* out, int B, int Ca, int Hs, int Ws,
+                           int n_freq, int R, int Ho, int Wo, int ld, int c_off, hands_stream_t stream) {
+  if (!angle || !mask || !out || B <= 0 || Ca <= 0 || Hs <= 0 || Ws <= 0 || n_freq < 0 || n_freq > 16 || R <= 0 || Ho <= 0 ||
+      Wo <= 0 || c_off < 0)
+    return HANDS_EINVAL;
+  const int Cenc = n_freq ? 2 * n_freq * Ca : Ca;
+  if (ld < c_off + Cenc || (img_nchw && c_off != 3)) return HANDS_EINVAL;
+  const long long n = (long long)B * Ho * Wo * (img_nchw ? ld : Cenc);
+  hipLaunchKernelGGL(dense_posenc_kernel, dim3(hands_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, angle, mask, img_nchw, out,
+                     B, Ca, Hs, Ws, n_freq, R, Ho, Wo, ld, c_off, Cenc);
+  HANDS_LAUNCH_CHECK();
+}
+
+int hands_concat_nhwc_f32(const float* a, int lda, int Ca, const float* add, int ld_add, const float* extra,
+                          long long extra_batch_stride, int Cb, float* out, int ld, int B, int Bg, int HW, hands_stream_t stream) {
+  if (!a || !out || B <= 0 || Bg <= 0 || HW <= 0 || Ca <= 0 || lda < Ca || Cb < 0 || (Cb && !extra) || ld < Ca + Cb ||
+      (add && ld_add < Ca))
+    return HANDS_EINVAL;
+  const long long n = (long long)B * HW * ld;
+  hipLaunchKernelGGL(concat_nhwc_kernel, dim3(hands_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, a, lda, Ca, add, ld_add,
+                     extra, extra_batch_stride, Cb, out, ld, B, Bg, HW);
+  HANDS_LAUNCH_CHECK();
+}
+
+int hands_upsample_bilinear_ac_f32(const float* x, float* out, int B, int h, int w, int H, int W, int C, hands_stream_t stream) {
+  if (!x || !out || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4) return HANDS_EINVAL;
+  const long long n = (long long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(upsample_bilinear_ac_kernel, dim3(hands_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)x, (float4*)out, B, h, w, H, W, C / 4);
+  HANDS_LAUNCH_CHECK();
+}
+
+int hands_rot_leftmul_f32(float* rotmat, const float* rot, int B, hands_stream_t stream) {
+  if (!rotmat || !rot || B <= 0) return HANDS_EINVAL;
+  hipLaunchKernelGGL(rot_leftmul_kernel, dim3(hands_grid_1d(B, 256)), dim3(256), 0, (hipStream_t)stream, rotmat, rot, B);
+  HANDS_LAUNCH_CHECK();
+}
+
+int hands_perspective_correction_f32(float* rot_swapped, float* rotmat, const float* center_angle, const int64_t* is_flipped,
+                                     int Bg, hands_stream_t stream) {
+  if (!rot_swapped || !rotmat || !center_angle || !is_flipped || Bg <= 0) return HANDS_EINVAL;
+  hipLaunchKernelGGL(persp_correct_kernel, dim3(hands_grid_1d(2LL * Bg, 256)), dim3(256), 0, (hipStream_t)stream, rot_swapped,
+                     rotmat, center_angle, (const long long*)is_flipped, Bg);
   HANDS_LAUNCH_CHECK();
 }
 

@@ -180,7 +180,44 @@ __global__ void __launch_bounds__(256) warp_cubic_norm_kernel(WarpArgs a) {
   }
 }
 
+
+// ---- per-pixel angle maps of a crop window (pos_enc 'dense' / 'dense_latent' / 'cam_conv') ----------------------------------
+// hands_light_dataset.py:281-333: for the window's pixels x in [x0, x1], y in [y0, y1] (first map index = x: meshgrid 'ij')
+// angle = atan2(x - cx, fx), atan2(y - cy, fy) in double (int64 grid - float32 intrinsic -> float64), stored as float32 in the
+// top-left corner of a zero (img_res, img_res) map; 'cam_conv' adds the centred offsets x - cx, y - cy and 2 x / img_res - 1,
+// 2 y / img_res - 1; the mask marks the window.
+__global__ void dense_maps_kernel(const int32_t* __restrict__ bbox, const float* __restrict__ K, float* __restrict__ angle,
+                                  float* __restrict__ mask, int B, int R, int nch) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= R * R) return;
+  const int i = p / R, j = p - i * R;
+  const int x0 = bbox[b * 4], y0 = bbox[b * 4 + 1], x1 = bbox[b * 4 + 2], y1 = bbox[b * 4 + 3];
+  const bool in = i <= x1 - x0 && j <= y1 - y0;
+  const float* Kb = K + b * 9;
+  float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (in) {
+    const double dx = (double)(x0 + i) - (double)Kb[2], dy = (double)(y0 + j) - (double)Kb[5];
+    v[0] = (float)atan2(dx, (double)Kb[0]);
+    v[1] = (float)atan2(dy, (double)Kb[4]);
+    v[2] = (float)dx;
+    v[3] = (float)dy;
+    v[4] = (float)(2.0 * (double)(x0 + i) / (double)R - 1.0);
+    v[5] = (float)(2.0 * (double)(y0 + j) / (double)R - 1.0);
+  }
+  for (int c = 0; c < nch; ++c) angle[((size_t)b * nch + c) * R * R + p] = v[c];
+  mask[(size_t)b * R * R + p] = in ? 1.f : 0.f;
+}
+
 }  // namespace
+
+extern "C" int hands_frontend_dense_maps_f32(const int32_t* bbox, const float* K, float* angle, float* mask, int B, int img_res,
+                                             int nch, hands_stream_t stream) {
+  if (!bbox || !K || !angle || !mask || B <= 0 || B > 65535 || img_res < 1 || (nch != 2 && nch != 6)) return HANDS_EINVAL;
+  hipLaunchKernelGGL(dense_maps_kernel, dim3((img_res * img_res + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, bbox, K, angle,
+                     mask, B, img_res, nch);
+  HANDS_LAUNCH_CHECK();
+}
 
 extern "C" int hands_frontend_boxes_f32(const float* j2d_r, const float* j2d_l, int ld, const float* K, int B,
                                         int img_res, int out_res, double bbox_scale,

@@ -6,8 +6,9 @@ test-time branch of ``HandsLightDataset.__getitem__`` (src/datasets/hands_light_
 (common/data_utils.py:495-509), the cubic crop-resize (``cv2.warpAffine`` inside
 ``generate_patch_image_clean``, common/data_utils.py:423-460), clip + ImageNet ``Normalize``, and
 the center / corner KPE angles.  It returns the ``inputs`` dict ``HandsLight.forward`` consumes
-(``img, r_img, l_img, r_bbox, l_bbox, r_bbox_og, l_bbox_og, {r,l}_center_angle, {r,l}_corner_angle``),
-all on the device.  ``img`` is the (B,3,res,res) RGB image in [0,1] that ``rgb_processing``
+(``img, r_img, l_img, r_bbox, l_bbox, r_bbox_og, l_bbox_og, {r,l}_center_angle, {r,l}_corner_angle``, and with a
+per-pixel encoding -- pos_enc 'dense' / 'dense_latent' / 'cam_conv' -- ``{r,l}_dense_angle, {r,l}_dense_mask``,
+hands_light_dataset.py:281-333), all on the device.  ``img`` is the (B,3,res,res) RGB image in [0,1] that ``rgb_processing``
 (common/data_utils.py:182-204) produces; decoding and that first full-frame crop stay with the caller.
 """
 from __future__ import annotations
@@ -32,8 +33,8 @@ class HandsFrontEnd:
         self.mean = tuple(float(v) for v in g("img_norm_mean", IMG_NORM_MEAN))
         self.std = tuple(float(v) for v in g("img_norm_std", IMG_NORM_STD))
         pos_enc = g("pos_enc", "center+corner_latent")
-        if pos_enc is not None and "dense" in pos_enc:
-            raise NotImplementedError("dense positional-encoding inputs are not built (configs/hands_light.py:8 default is center+corner_latent)")
+        # per-pixel maps of the crop windows (hands_light_dataset.py:281-333): 2 angle maps, or 6 maps for 'cam_conv'
+        self.dense_channels = 0 if pos_enc is None else 6 if "cam_conv" in pos_enc else 2 if "dense" in pos_enc else 0
         if g("no_intrx", False):
             raise NotImplementedError("no_intrx front-end variant is not built (configs/hands_light.py:29 default False)")
 
@@ -58,6 +59,13 @@ class HandsFrontEnd:
                                          ptr(o["r_trans"]), ptr(o["l_trans"]), ptr(o["r_center_angle"]), ptr(o["l_center_angle"]),
                                          ptr(o["r_corner_angle"]), ptr(o["l_corner_angle"]),
                                          torch.cuda.current_stream(dev).cuda_stream), "hands_frontend_boxes_f32")
+        if self.dense_channels:
+            R, n = self.img_res, self.dense_channels
+            for h in "rl":
+                o[f"{h}_dense_angle"] = torch.empty(B, n, R, R, device=dev)
+                o[f"{h}_dense_mask"] = torch.empty(B, R, R, device=dev)
+                check(L.hands_frontend_dense_maps_f32(ptr(o[f"{h}_bbox"]), ptr(K), ptr(o[f"{h}_dense_angle"]), ptr(o[f"{h}_dense_mask"]),
+                                                      B, R, n, torch.cuda.current_stream(dev).cuda_stream), "hands_frontend_dense_maps_f32")
         for k in ("r_bbox", "l_bbox", "r_bbox_og", "l_bbox_og"):
             o[k] = o[k].to(torch.int16)                                   # the reference's dtype (astype(np.int16))
         return o
@@ -92,6 +100,7 @@ class HandsFrontEnd:
             t = torch.tensor([s, 0, 0, 0, s, 0], dtype=torch.float32, device=img.device).repeat(img.shape[0], 1)
             inputs["img"] = self.warp(img, t)
         for k in ("r_bbox", "l_bbox", "r_bbox_og", "l_bbox_og", "r_center_angle", "l_center_angle",
-                  "r_corner_angle", "l_corner_angle"):
+                  "r_corner_angle", "l_corner_angle") + (("r_dense_angle", "l_dense_angle", "r_dense_mask", "l_dense_mask")
+                                                         if self.dense_channels else ()):
             inputs[k] = o[k]
         return inputs

@@ -17,10 +17,11 @@ statement of ``forward`` runs as a hand-written gfx950 kernel from ``libhands_hi
     :401-404      grasp classifier            hands_grasp_input_f32, hands_conv2d_nhwc_f32 x4
 
 torch is used for parameter containers, device buffers and streams only.  Built configurations: resnet50,
-shared hand backbone, use_glb_feat, tf_decoder=False with pos_enc in {'center+corner_latent' (shipped default),
-'sinusoidal_cc', 'center', 'corner', 'center+corner', None}, ``no_crops`` (arctic_light), the grasp head with / without
-the global feature vector or absent, ``separate_hands``, ``regress_center_corner``, ``use_glb_feat=False``; the remaining
-switches (tf_decoder, dense / pcl encodings, depth and renderer heads) raise ``NotImplementedError``.
+tf_decoder=False with every pos_enc of model.py -- 'center+corner_latent' (shipped default), 'sinusoidal_cc', 'center', 'corner',
+'center+corner', 'dense', 'dense_latent', 'cam_conv', 'pcl', 'perspective_correction', None -- ``no_crops`` (arctic_light), the
+grasp head with / without the global feature vector or absent, ``separate_hands``, ``regress_center_corner``,
+``use_glb_feat=False``, ``use_depth_loss`` (the depth head); tf_decoder, the ViT backbone and the renderer raise
+``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -282,8 +283,15 @@ class HandsLight(EngineSwitches, nn.Module):
         # the grasp head with and without the global feature vector, or absent.
         pos_enc = get("pos_enc")
         self.pos_enc = pos_enc
+        # 'dense' (per-pixel angle maps as extra conv1 channels, model.py:220-224), 'dense_latent' / 'cam_conv' (the maps resized
+        # to the 7x7 feature map and concatenated, :244-256 / :276-288), 'pcl' / 'perspective_correction' (no encoding; the global
+        # rotation is corrected after the heads, :330-334 / :370-376)
         self.enc_mode = ("latent" if pos_enc in LATENT_ENC else "image" if pos_enc in IMAGE_ENC else
-                         "none" if pos_enc is None else None)
+                         "dense" if pos_enc == "dense" else "dense_latent" if pos_enc in ("dense_latent", "cam_conv") else
+                         "none" if pos_enc in (None, "pcl", "perspective_correction") else None)
+        self.rot_fix = {"pcl": 1, "perspective_correction": 2}.get(pos_enc, 0)
+        self.use_depth_loss = bool(get("use_depth_loss", False))
+        self.img_res_ds = int(get("img_res_ds", img_res) or img_res)
         self.no_crops = bool(get("no_crops", False))
         self.use_grasp_loss = bool(get("use_grasp_loss", False))
         self.use_glb_feat_w_grasp = bool(get("use_glb_feat_w_grasp", False))
@@ -291,9 +299,9 @@ class HandsLight(EngineSwitches, nn.Module):
         self.regress_center_corner = bool(get("regress_center_corner", False))   # model.py:157-172, 426-433
         self.use_glb_feat = bool(get("use_glb_feat", False))
         unsupported = {
-            f"pos_enc={pos_enc!r}": self.enc_mode is None,     # 'pcl', 'perspective_correction', 'dense', 'dense_latent', 'cam_conv'
+            f"pos_enc={pos_enc!r}": self.enc_mode is None,
             "tf_decoder": bool(get("tf_decoder", False)),
-            "use_depth_loss": bool(get("use_depth_loss", False)),
+            "use_depth_loss with no_crops": self.use_depth_loss and self.no_crops,      # `depth_r` undefined in the reference (:308-310, 422)
             "use_render_seg_loss": bool(get("use_render_seg_loss", False)),
             # the reference itself fails on these combinations (`features` / `feat_vec` undefined, model.py:191-201, 402-404;
             # center_head on a 4-D map, :428)
@@ -309,7 +317,8 @@ class HandsLight(EngineSwitches, nn.Module):
         self.feat_dim = feat_dim
         self.backbone = ResNet50Params()      # (the reference builds it even with use_glb_feat = False: same state_dict keys)
         # model.py:60-77: conv1 of the hand trunk takes the image-level encoding as extra input channels
-        self.enc_channels = {1: 4, 2: 16, 3: 20}[IMAGE_ENC[pos_enc]] * self.n_freq if self.enc_mode == "image" else 0
+        self.enc_channels = ({1: 4, 2: 16, 3: 20}[IMAGE_ENC[pos_enc]] * self.n_freq if self.enc_mode == "image" else
+                             4 * self.n_freq if self.enc_mode == "dense" else 0)
         if self.separate_hands:
             self.hand_backbone_r = ResNet50Params(3 + self.enc_channels)
             self.hand_backbone_l = ResNet50Params(3 + self.enc_channels)
@@ -317,7 +326,9 @@ class HandsLight(EngineSwitches, nn.Module):
             self.hand_backbone = ResNet50Params(3 + self.enc_channels)
         self.head_r = HandHMR(feat_dim, True, 3)
         self.head_l = HandHMR(feat_dim, False, 3)
-        fc_dim = feat_dim + (5 * 4 * self.n_freq if self.enc_mode == "latent" else 0)       # model.py:79-88
+        self.latent_channels = (5 * 4 * self.n_freq if self.enc_mode == "latent" else 4 * self.n_freq if pos_enc == "dense_latent" else
+                                6 if pos_enc == "cam_conv" else 0)
+        fc_dim = feat_dim + self.latent_channels                                           # model.py:79-88
         self.feature_conv = nn.Sequential(
             nn.Conv2d(fc_dim, 1024, 1, bias=False), nn.ReLU(inplace=True),
             nn.Conv2d(1024, 512, 3, bias=False), nn.ReLU(inplace=True),
@@ -331,6 +342,13 @@ class HandsLight(EngineSwitches, nn.Module):
             self.grasp_classifier = nn.Sequential(
                 nn.Linear(gdim, 1024), nn.ReLU(inplace=True), nn.Linear(1024, 512),
                 nn.ReLU(inplace=True), nn.Linear(512, 128), nn.ReLU(inplace=True), nn.Linear(128, 9))
+        if self.use_depth_loss:                                                            # model.py:133-155
+            cv = lambda i, o: nn.Conv2d(i, o, 3, 1, 1)
+            up = lambda k: nn.Upsample(scale_factor=k, mode="bilinear", align_corners=True)
+            self.depth_mlp = nn.Sequential(
+                cv(fc_dim + 2, 256), nn.ReLU(True), cv(256, 256), nn.ReLU(True), up(4), cv(256, 128), nn.ReLU(True),
+                cv(128, 128), nn.ReLU(True), up(4), cv(128, 64), nn.ReLU(True), cv(64, 32), nn.ReLU(True), up(2),
+                cv(32, 16), nn.ReLU(True), cv(16, 1))
         if self.regress_center_corner:
             mk = lambda n: nn.Sequential(nn.Linear(feat_dim, 512), nn.ReLU(inplace=True), nn.Linear(512, 128),
                                          nn.ReLU(inplace=True), nn.Linear(128, n))
@@ -432,7 +450,16 @@ class HandsLight(EngineSwitches, nn.Module):
                 P[nm] = [pack_linear(cpu(head[0].weight), cpu(head[0].bias), dev), pack_linear(cpu(head[2].weight), cpu(head[2].bias), dev),
                          pack_linear(cpu(head[4].weight), cpu(head[4].bias), dev, n_total=8)]
         fc = self.feature_conv
-        P["fc0"] = pack_conv(cpu(fc[0].weight), None, 1, 0, dev)
+        # 'dense_latent' / 'cam_conv': the concatenated map is stored with its channel count padded to a multiple of 16 (zeros)
+        P["fc0"] = pack_conv(cpu(fc[0].weight), None, 1, 0, dev,
+                             cin_pad_to=self._cat_ld() if self.enc_mode == "dense_latent" else None)
+        if self.use_depth_loss:
+            dm = self.depth_mlp
+            P["depth"] = [pack_conv(cpu(dm[i].weight), cpu(dm[i].bias), 1, 1, dev,
+                                    cin_pad_to=self._depth_ld() if i == 0 else None) for i in (0, 2, 5, 7, 10, 12, 15, 17)]
+            lin = torch.linspace(-1, 1, 7)                                # model.py:172-175 (`init_grid`, 'ij' meshgrid)
+            xg, yg = torch.meshgrid(lin, lin, indexing="ij")
+            P["depth_grid"] = torch.stack([xg, yg], dim=-1).reshape(49, 2).contiguous().to(dev)
         P["fc2"] = pack_conv(cpu(fc[2].weight), None, 1, 0, dev)
         P["fc4"] = pack_conv(cpu(fc[4].weight), None, 1, 0, dev)
         # nn.Flatten on NCHW (B,256,3,3): reference column c*9 + hw; NHWC buffer column hw*256 + c
@@ -453,6 +480,14 @@ class HandsLight(EngineSwitches, nn.Module):
             m = P[side]
             m["consts"] = mano_consts(m)
         return P
+
+    def _cat_ld(self):
+        """Row length of the map feature_conv reads (model.py:79-88): F + encoding channels, padded to 16 for the per-pixel modes."""
+        n = self.feat_dim + self.latent_channels
+        return (n + 15) // 16 * 16 if self.enc_mode == "dense_latent" else n
+
+    def _depth_ld(self):
+        return (self.feat_dim + self.latent_channels + 2 + 15) // 16 * 16
 
     def replica(self):
         """A second handle on the SAME parameters and packed weights with its own workspaces, side
@@ -607,9 +642,36 @@ class HandsLight(EngineSwitches, nn.Module):
         if self.separate_hands and hch:
             hch = 2                # one job per side: the sides have their own weights (model.py:226-228)
         gch, hch = (max(1, min(gch, bz)) if self.use_glb_feat else 0), min(hch, B2)
-        center = torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0) if self.enc_mode != "none" else None
-        corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0) if self.enc_mode != "none" else None
+        need_cc = self.enc_mode in ("latent", "image")
+        center = (torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
+                  if (need_cc or self.rot_fix == 2) else None)
+        corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0) if need_cc else None
+        rot_in = torch.cat([f32(inputs["r_rot"]), f32(inputs["l_rot"])], 0) if self.rot_fix == 1 else None    # 'pcl' (B2, 3, 3)
         wide = None
+        dense_enc = None
+        if self.enc_mode in ("dense", "dense_latent") and not self.no_crops:
+            # model.py:462-481: per-pixel angle maps (bz, 2 | 6, w, h) + crop masks, encoded / masked / resized on the device
+            ang = [f32(inputs["r_dense_angle"]), f32(inputs["l_dense_angle"])]
+            msk = [f32(inputs["r_dense_mask"]), f32(inputs["l_dense_mask"])]
+            Ca, Hs, Ws = ang[0].shape[1:]
+            L_enc = 0 if self.pos_enc == "cam_conv" else self.n_freq
+            assert (2 * L_enc * Ca if L_enc else Ca) == (self.enc_channels if self.enc_mode == "dense" else self.latent_channels)
+            if self.enc_mode == "dense":
+                # model.py:220-224: cat([crop, encoding]) as the NHWC input of the widened conv1
+                assert res == self.img_res_ds, "pos_enc='dense': the crops must have the size args.img_res_ds"
+                Cp = P["hand_backbone_r" if self.separate_hands else "hand_backbone"]["stem_wide"].Cin
+                wide = buf("wide_in", B2 * res * res * Cp)
+                for side, im in enumerate((r_img, l_img)):
+                    check(L.hands_dense_posenc_f32(ptr(ang[side]), ptr(msk[side]), ptr(im), ptr(wide, side * bz * res * res * Cp),
+                                                   bz, Ca, Hs, Ws, L_enc, self.img_res_ds, res, res, Cp, 3, stream), "dense_posenc")
+            else:
+                # model.py:244-249 / 276-281: resized to img_res_ds and then to the 7x7 feature map -- an input-only computation,
+                # done here on the caller's stream so that the tail never reads the caller's maps
+                Ce = self.latent_channels
+                dense_enc = buf(f"dense_enc{par}", B2 * 49 * Ce)
+                for side in (0, 1):
+                    check(L.hands_dense_posenc_f32(ptr(ang[side]), ptr(msk[side]), None, ptr(dense_enc, side * bz * 49 * Ce),
+                                                   bz, Ca, Hs, Ws, L_enc, self.img_res_ds, 7, 7, Ce, 0, stream), "dense_posenc")
         if self.enc_mode == "image" and not self.no_crops:
             # model.py:203-218: cat([crop, enc repeated over the pixels]) as the NHWC input of the widened conv1
             Cp = P["hand_backbone_r" if self.separate_hands else "hand_backbone"]["stem_wide"].Cin
@@ -660,13 +722,13 @@ class HandsLight(EngineSwitches, nn.Module):
             evt = torch.cuda.Event()
             evt.record(main)
             tail.wait_event(evt)
-            for t in (center, corner, K, flipped):
+            for t in (center, corner, K, flipped, rot_in):
                 if t is not None:
                     t.record_stream(tail)
         else:
             tail = main
         with torch.cuda.stream(tail):
-            output = self._forward_tail(L, P, dev, tail, bz, fh, fw, featg, feath, center, corner, K, flipped)
+            output = self._forward_tail(L, P, dev, tail, bz, fh, fw, featg, feath, center, corner, K, flipped, dense_enc, rot_in)
         if not async_tail:
             return output
         ready = torch.cuda.Event()
@@ -674,7 +736,35 @@ class HandsLight(EngineSwitches, nn.Module):
         self._ws[f"tail_done{par}"] = ready
         return stream_xdict(output, ready, dev)
 
-    def _forward_tail(self, L, P, dev, main, bz, fh, fw, featg, feath, center, corner, K, flipped):
+    def _depth_head(self, L, P, dev, stream, cat, B2, bz, fh, fw):
+        """`predict_depth` (model.py:177-185, 438-441) on the map feature_conv reads: (x, y) grid channels appended, eight 3x3 / pad 1
+        convolutions, three align_corners upsamplings (7 -> 28 -> 112 -> 224).  Returns (depth.r, depth.l), each (bz, 224, 224)."""
+        F = self.feat_dim
+        Cr, lda, ldd = F + self.latent_channels, (self._cat_ld() if self.enc_mode in ("latent", "dense_latent") else F), self._depth_ld()
+        d = P["depth"]
+        out = torch.empty(B2, 16 * fh * 2, 16 * fw * 2, device=dev)
+        step = 256                       # images per pass: the 224 x 224 x 32 map of 256 crops is 1.6 GB (and < 2^31 floats)
+        for lo in range(0, B2, step):
+            n = min(step, B2 - lo)
+            buf = lambda nm, numel: self._buf(nm, numel, dev)
+            din = buf("depth_in", n * fh * fw * ldd)
+            check(L.hands_concat_nhwc_f32(ptr(cat, lo * fh * fw * lda), lda, Cr, None, 0, ptr(P["depth_grid"]), 0, 2, ptr(din), ldd,
+                                          n, n, fh * fw, stream), "depth_in")
+            h, w = fh, fw
+            x = din
+            for i, pc in enumerate(d):
+                y = buf(f"depth_c{i}", n * h * w * pc.Cout)
+                self.engine.conv(L, pc, x, n, h, w, y, i < 7, stream)
+                x = y
+                if i in (1, 3, 5):                            # nn.Upsample(x4, x4, x2; bilinear, align_corners=True)
+                    k = 2 if i == 5 else 4
+                    u = buf(f"depth_u{i}", n * h * k * w * k * pc.Cout)
+                    check(L.hands_upsample_bilinear_ac_f32(ptr(x), ptr(u), n, h, w, h * k, w * k, pc.Cout, stream), "upsample_ac")
+                    x, h, w = u, h * k, w * k
+            out[lo:lo + n] = x[: n * h * w * 4].view(n, h, w, 4)[..., 0]      # Cout = 1 stored with a pixel stride of 4 floats
+        return out[:bz], out[bz:]
+
+    def _forward_tail(self, L, P, dev, main, bz, fh, fw, featg, feath, center, corner, K, flipped, dense_enc=None, rot_in=None):
         """Everything after the trunks (model.py:196-411), enqueued on ``main`` (the tail stream)."""
         B2, F, HW = 2 * bz, self.feat_dim, fh * fw
         stream = main.cuda_stream
@@ -697,8 +787,15 @@ class HandsLight(EngineSwitches, nn.Module):
                 cat = buf("cat", B2 * HW * Cc)
                 check(L.hands_kpe_concat_f32(ptr(feath), ptr(featg) if self.use_glb_feat else None, ptr(center), ptr(corner),
                                              ptr(cat), B2, bz, HW, F, self.n_freq, stream), "kpe_concat")
+            elif self.enc_mode == "dense_latent":
+                # -- cat([features (+ global features), resized per-pixel maps]) (model.py:250-256, 282-288) -------------------
+                Cc, Ce = self._cat_ld(), self.latent_channels
+                cat = buf("cat", B2 * HW * Cc)
+                check(L.hands_concat_nhwc_f32(ptr(feath), F, F, ptr(featg) if self.use_glb_feat else None, F, ptr(dense_enc),
+                                              HW * Ce, Ce, ptr(cat), Cc, B2, bz, HW, stream), "concat")
             else:
                 cat = feath            # pos_enc None / image-level: feature_conv reads the crop features as they are
+            depth = self._depth_head(L, P, dev, stream, cat, B2, bz, fh, fw) if self.use_depth_loss else None
             # -- feature_conv (model.py:91-101, 313-314) -> HMR state rows ---------------------------
             f1 = buf("fc1", B2 * HW * 1024)
             self.engine.conv(L, P["fc0"], cat, B2, fh, fw, f1, True, stream)
@@ -741,6 +838,8 @@ class HandsLight(EngineSwitches, nn.Module):
             main.wait_event(ev)
         rotmat = buf("rotmat", B2 * 144)
         check(L.hands_rot6d_to_matrix_f32(ptr(state, F), ld, ptr(rotmat), B2, stream), "rot6d")
+        if self.rot_fix == 1:      # 'pcl' (model.py:330-334): in place on the heads' output -- the flip swap and the grasp head see it
+            check(L.hands_rot_leftmul_f32(ptr(rotmat), ptr(rot_in), B2, stream), "rot_leftmul")
         st = state[: B2 * ld].view(B2, ld)
         shape = st[:, F + 96:F + 106].contiguous()
         cam = st[:, F + 108:F + 111].contiguous()
@@ -754,6 +853,9 @@ class HandsLight(EngineSwitches, nn.Module):
         check(L.hands_flip_swap_f32(ptr(flipped), ptr(rotmat), ptr(shape), ptr(cam), ptr(caminit),
                                     ptr(rot_m), ptr(shape_m), ptr(cam_m), ptr(caminit_m), bz, stream),
               "flip_swap")
+
+        if self.rot_fix == 2:      # 'perspective_correction' (model.py:370-376): after the swap, see hands_hip.h for the grasp quirk
+            check(L.hands_perspective_correction_f32(ptr(rot_m), ptr(rotmat), ptr(center), ptr(flipped), bz, stream), "persp")
 
         # -- MANOHead x2 (mano_head.py:21-65) -----------------------------------------------------
         output = run_mano_heads(L, P["mano_r"], P["mano_l"], rot_m, shape_m, cam_m, caminit_m, K,
@@ -774,6 +876,14 @@ class HandsLight(EngineSwitches, nn.Module):
                 extra[key + ".r"] = o[:bz, :n].contiguous()
                 extra[key + ".l"] = o[bz:, :n].contiguous()
         # -- grasp classifier on the UN-flipped HMR outputs (model.py:401-411) -------------------
+        if self.use_depth_loss and not self.no_crops:          # model.py:420-424 (merged after the grasp outputs, before center / corner)
+            dx = xdict()
+            dx["depth.r"], dx["depth.l"] = depth
+            if extra is None:
+                extra = dx
+            else:
+                dx.merge(extra)
+                extra = dx
         if not self.use_grasp_loss:
             if extra is not None:
                 output.merge(extra)

@@ -167,3 +167,38 @@ def synthetic_inputs(bz: int, seed: int = 0, img_res: int = 224, device="cpu"):
     inputs = {k: v.to(device) for k, v in inputs.items()}
     meta_info = {k: v.to(device) for k, v in meta_info.items()}
     return inputs, meta_info
+
+
+def synthetic_dense_inputs(bz: int, seed: int = 0, pos_enc: str = "dense", img_res: int = 224, device="cpu"):
+    """The extra per-sample inputs of the non-default encodings, shaped as the reference's datasets build them
+    (src/datasets/assembly_dataset.py:496-548, 569-681): ``{r,l}_dense_angle`` (bz, 2 | 6, img_res, img_res) -- the per-pixel
+    viewing angles of the crop box (plus, for 'cam_conv', the centred pixel offsets and the normalised coordinates), zero outside
+    the box -- with ``{r,l}_dense_mask`` (bz, img_res, img_res), and for 'pcl' the virtual-to-original rotations ``{r,l}_rot``."""
+    g = torch.Generator().manual_seed(10_000 + seed)
+    out = {}
+    if pos_enc == "pcl":
+        for side in "rl":
+            w = 0.2 * torch.randn(bz, 3, generator=g)
+            skew = torch.zeros(bz, 3, 3)
+            skew[:, 0, 1], skew[:, 0, 2], skew[:, 1, 2] = -w[:, 2], w[:, 1], -w[:, 0]
+            skew = skew - skew.transpose(1, 2)
+            out[f"{side}_rot"] = torch.linalg.matrix_exp(skew.double()).float()
+        return {k: v.to(device) for k, v in out.items()}
+    f, c0 = 1000.0, img_res / 2
+    for side in "rl":
+        nch = 6 if pos_enc == "cam_conv" else 2
+        ang = torch.zeros(bz, nch, img_res, img_res)
+        msk = torch.zeros(bz, img_res, img_res)
+        for b in range(bz):
+            x0, y0 = (int(v) for v in torch.randint(0, 400, (2,), generator=g))
+            w, h = (int(v) for v in torch.randint(100, img_res + 1, (2,), generator=g))
+            xs = torch.arange(x0, x0 + w, dtype=torch.float64)[:, None].expand(w, h)
+            ys = torch.arange(y0, y0 + h, dtype=torch.float64)[None, :].expand(w, h)
+            maps = [torch.atan2(xs - c0, torch.tensor(f, dtype=torch.float64)), torch.atan2(ys - c0, torch.tensor(f, dtype=torch.float64))]
+            if nch == 6:
+                maps += [xs - c0, ys - c0, 2 * xs / img_res - 1, 2 * ys / img_res - 1]
+            for i, m in enumerate(maps):
+                ang[b, i, :w, :h] = m.float()
+            msk[b, :w, :h] = 1.0
+        out[f"{side}_dense_angle"], out[f"{side}_dense_mask"] = ang, msk
+    return {k: v.to(device) for k, v in out.items()}

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define HANDS_EINVAL 10001
-#define HANDS_ABI_VERSION 2
+#define HANDS_ABI_VERSION 3
 
 typedef void* hands_stream_t;
 
@@ -200,6 +200,39 @@ int hands_avgpool_nhwc_f32(const float* feat, float* out, int B, int HW, int C, 
  * is the input of the hand trunk's widened conv1 through hands_conv2d_nhwc_f32 (Cin = Cpad, a multiple of 16). */
 int hands_image_posenc_nhwc_f32(const float* img_nchw, const float* center_angle, const float* corner_angle, float* out,
                                 int B, int H, int W, int n_freq, int mode, int Cpad, hands_stream_t stream);
+
+
+/* Per-pixel positional encodings, pos_enc = 'dense' | 'dense_latent' | 'cam_conv' (src/models/hands_light/model.py:462-481, call
+ * sites :220-224, :244-256, :276-288).  angle (B, Ca, Hs, Ws) NCHW, mask (B, Hs, Ws).  n_freq > 0: the 2 n_freq Ca channels
+ * sin / cos(2^k angle[ci]) laid out (k, ci, {sin, cos}); n_freq == 0: the Ca raw maps ('cam_conv'); times the mask; then
+ * F.interpolate(bilinear, align_corners=True) to (R, R) (args.img_res_ds) and from there to (Ho, Wo) (Ho == R: the first only).
+ * The result goes to channels [c_off, c_off + Cenc) of the NHWC map out (B, Ho, Wo, ld).  img_nchw != NULL ((B, 3, Ho, Wo),
+ * c_off == 3): the whole pixel is written, [r g b | encoding | zeros] -- the input of the hand trunk's widened conv1
+ * ('dense'); NULL: only the encoding channels (the 7x7 map hands_concat_nhwc_f32 appends to the features). */
+int hands_dense_posenc_f32(const float* angle, const float* mask, const float* img_nchw, float* out, int B, int Ca, int Hs, int Ws,
+                           int n_freq, int R, int Ho, int Wo, int ld, int c_off, hands_stream_t stream);
+
+/* torch.cat along the channels of NHWC maps: out[b, p, :] = [a[b, p, :Ca] (+ add[b % Bg, p, :Ca]) | extra[b, p, :Cb] | zeros],
+ * row strides lda / ld_add / Cb / ld, extra_batch_stride floats between samples of `extra` (0: one map for every sample).
+ * model.py:252-256, 284-288 (features (+ global features) with the resized per-pixel maps), :177-185 (`broadcast`: the depth
+ * head's (x, y) grid).  add / extra may be NULL (Cb = 0). */
+int hands_concat_nhwc_f32(const float* a, int lda, int Ca, const float* add, int ld_add, const float* extra,
+                          long long extra_batch_stride, int Cb, float* out, int ld, int B, int Bg, int HW, hands_stream_t stream);
+
+/* out (B, H, W, C) = nn.Upsample / F.interpolate(x (B, h, w, C), mode='bilinear', align_corners=True): the three upsamplings of
+ * the depth head (model.py:141, 146, 151).  C % 4 == 0. */
+int hands_upsample_bilinear_ac_f32(const float* x, float* out, int B, int h, int w, int H, int W, int C, hands_stream_t stream);
+
+/* pos_enc = 'pcl' (model.py:330-334): rotmat[b, 0] = rot[b] @ rotmat[b, 0] in place; rotmat (B, 16, 3, 3), rot (B, 3, 3). */
+int hands_rot_leftmul_f32(float* rotmat, const float* rot, int B, hands_stream_t stream);
+
+/* pos_enc = 'perspective_correction' (model.py:370-376): rot_swapped[b, 0] = Rx(-c[b,0]) Ry(-c[b,1]) @ rot_swapped[b, 0] on the
+ * rotations AFTER the is_flipped swap (2 Bg rows: right then left; center_angle (2 Bg, 2)).  pytorch3d.euler_angles_to_matrix
+ * ('XYZ') is absent from the reference tree: published definition, parity unpinned.  The reference assigns in place: in a batch
+ * without a flipped sample that tensor is the heads' own output, which the grasp head reads afterwards -- the corrected matrix
+ * is then also written to rotmat (the unswapped rotations); with a flipped sample rotmat stays as it is. */
+int hands_perspective_correction_f32(float* rot_swapped, float* rotmat, const float* center_angle, const int64_t* is_flipped,
+                                     int Bg, hands_stream_t stream);
 
 /* out[b2, p, :] = cat(crop[b2,p,:] + glb[b2 % Bg, p, :], center_enc(b2), corner_enc(b2)).
  * crop holds the right-hand samples then the left-hand samples (2*Bg rows); encodings are the
@@ -453,6 +486,14 @@ int hands_unnormalize_kp2d_f32(const float* x, float* out, long long n, float im
  *   trans (B,6) device pointer or NULL for the identity; mean3/std3 are HOST pointers to 3 floats.
  *   OpenCV is not vendored by the reference: the kernel follows its published fixed-point cubic
  *   remap (see oracle/frontend_oracle.py, "parity unpinned"). */
+/* Per-pixel maps of the crop windows for pos_enc 'dense' / 'dense_latent' (nch = 2) and 'cam_conv' (nch = 6)
+ * (src/datasets/hands_light_dataset.py:281-333): angle (B, nch, img_res, img_res) = atan2(x - cx, fx), atan2(y - cy, fy)
+ * (, x - cx, y - cy, 2 x / img_res - 1, 2 y / img_res - 1) for the window pixels x in [x0, x1], y in [y0, y1] -- first map index x
+ * -- in the top-left corner of a zero map; mask (B, img_res, img_res) = 1 on the window.  bbox (B, 4) int32 [x0, y0, x1, y1] as
+ * written by hands_frontend_boxes_f32, K (B, 3, 3).  The inputs of hands_dense_posenc_f32. */
+int hands_frontend_dense_maps_f32(const int32_t* bbox, const float* K, float* angle, float* mask, int B, int img_res, int nch,
+                                  hands_stream_t stream);
+
 int hands_frontend_boxes_f32(const float* j2d_r, const float* j2d_l, int ld, const float* K, int B,
                              int img_res, int out_res, double bbox_scale,
                              int32_t* bbox_r, int32_t* bbox_l, int32_t* bbox_og_r, int32_t* bbox_og_l,

@@ -214,6 +214,27 @@ def kpe_angles(bbox_xyxy, K):
     return center_angle, corner_angle
 
 
+def dense_maps(bbox_xyxy, K, img_res=224, cam_conv=False):
+    """hands_light_dataset.py:281-300 ('dense' / 'dense_latent') and :302-333 ('cam_conv'): per-pixel viewing angles of the crop
+    window (first index x: meshgrid 'ij') -- int64 grid minus the float32 intrinsic is float64, atan2 runs in double -- in the
+    top-left corner of a zero (img_res, img_res) map, plus the window mask.  -> (angle (2 | 6, R, R), mask (R, R)) float32."""
+    b = [int(v) for v in np.asarray(bbox_xyxy)]
+    K = np.asarray(K)
+    xg, yg = np.meshgrid(range(b[0], b[2] + 1), range(b[1], b[3] + 1), indexing="ij")
+    pix = np.stack([xg - K[0, 2], yg - K[1, 2]], axis=-1)
+    ang = np.arctan2(pix, np.array([[K[0, 0], K[1, 1]]])).transpose(2, 0, 1).astype(np.float32)
+    maps = [ang]
+    if cam_conv:
+        maps.append(pix.transpose(2, 0, 1).astype(np.float32))
+        maps.append(np.stack([2 * xg / img_res - 1, 2 * yg / img_res - 1], axis=-1).transpose(2, 0, 1).astype(np.float32))
+    maps = np.concatenate(maps, 0)
+    out = np.zeros((maps.shape[0], img_res, img_res))
+    out[:, :maps.shape[1], :maps.shape[2]] = maps
+    mask = np.zeros((img_res, img_res))
+    mask[:maps.shape[1], :maps.shape[2]] = 1
+    return out.astype(np.float32), mask.astype(np.float32)
+
+
 # ------------------------------------------------------------------------------------------------
 # whole front-end for one sample (test-time branch)
 # ------------------------------------------------------------------------------------------------

@@ -332,13 +332,60 @@ def image_level_input(img, center_angle, corner_angle, mode, n_freq=4):
     return torch.cat(parts, dim=1)
 
 
+def dense_pos_enc(angle, mask, n_freq=4, img_res_ds=224):
+    """model.py:462-472: per-pixel encodings of the (bz, c, w, h) angle maps -- cat([sin, cos], dim=3) of the
+    (bz, L, c, w, h) products reshaped to (bz, 2 L c, w, h), i.e. channel (l c + ci) 2 + {sin, cos} -- times the crop mask,
+    then F.interpolate(bilinear, align_corners=True) to the trunk's input size."""
+    bz, c, w, h = angle.shape
+    freq = (2 ** torch.arange(n_freq)).reshape(1, n_freq, 1, 1, 1).to(angle.device)
+    a = angle.reshape(bz, 1, c, w, h)
+    enc = torch.cat([torch.sin(freq * a), torch.cos(freq * a)], dim=3).reshape(bz, -1, w, h).float()
+    enc = enc * mask.unsqueeze(1).repeat(1, 2 * n_freq * c, 1, 1)
+    return F.interpolate(enc, size=(img_res_ds, img_res_ds), mode="bilinear", align_corners=True)
+
+
+def cam_conv_pos_enc(angle, mask, img_res_ds=224):
+    """model.py:474-481: the masked (bz, 6, w, h) maps (angles, centred pixel offsets, normalised coordinates) resized as above."""
+    angle = angle * mask.unsqueeze(1).repeat(1, angle.shape[1], 1, 1)
+    return F.interpolate(angle, size=(img_res_ds, img_res_ds), mode="bilinear", align_corners=True)
+
+
+def euler_angles_to_matrix_xyz(e):
+    """pytorch3d.transforms.euler_angles_to_matrix(e, 'XYZ') (call site model.py:370-376; third party, absent: PARITY
+    UNPINNED, published definition): Rx(e0) @ Ry(e1) @ Rz(e2) with the right-handed elementary rotations."""
+    c, s = torch.cos(e), torch.sin(e)
+    one, zero = torch.ones_like(c[..., 0]), torch.zeros_like(c[..., 0])
+    rx = torch.stack([one, zero, zero, zero, c[..., 0], -s[..., 0], zero, s[..., 0], c[..., 0]], -1).reshape(e.shape[:-1] + (3, 3))
+    ry = torch.stack([c[..., 1], zero, s[..., 1], zero, one, zero, -s[..., 1], zero, c[..., 1]], -1).reshape(e.shape[:-1] + (3, 3))
+    rz = torch.stack([c[..., 2], -s[..., 2], zero, s[..., 2], c[..., 2], zero, zero, zero, one], -1).reshape(e.shape[:-1] + (3, 3))
+    return torch.matmul(torch.matmul(rx, ry), rz)
+
+
+def depth_head(x, sd, p="depth_mlp"):
+    """model.py:134-155, 177-185, 438-441: the 7x7 (x, y) grid of torch.meshgrid(linspace(-1,1,7), linspace(-1,1,7)) ('ij')
+    appended as two channels, then eight 3x3 / pad 1 convolutions with three align_corners bilinear upsamplings (x4, x4, x2)."""
+    bz = x.shape[0]
+    lin = torch.linspace(-1, 1, 7)
+    xg, yg = torch.meshgrid(lin, lin, indexing="ij")
+    x = torch.cat((x, xg.expand(bz, 1, -1, -1), yg.expand(bz, 1, -1, -1)), dim=1)
+    conv = lambda t, i: F.conv2d(t, sd[f"{p}.{i}.weight"], sd[f"{p}.{i}.bias"], padding=1)
+    up = lambda t, k: F.interpolate(t, scale_factor=k, mode="bilinear", align_corners=True)
+    x = F.relu(conv(x, 0)); x = F.relu(conv(x, 2)); x = up(x, 4)
+    x = F.relu(conv(x, 5)); x = F.relu(conv(x, 7)); x = up(x, 4)
+    x = F.relu(conv(x, 10)); x = F.relu(conv(x, 12)); x = up(x, 2)
+    x = F.relu(conv(x, 15))
+    return conv(x, 17)
+
+
 def hands_light_forward(sd, asset_r, asset_l, inputs, meta_info, img_res=224, n_freq=4,
                         return_intermediates=False, pos_enc_mode="center+corner_latent", no_crops=False,
                         use_grasp_loss=True, use_glb_feat_w_grasp=True, separate_hands=False, regress_center_corner=False,
-                        use_glb_feat=True):
-    """model.py:187-437 with use_glb_feat=True, shared hand backbone, tf_decoder=False.  ``pos_enc_mode``:
+                        use_glb_feat=True, use_depth_loss=False, img_res_ds=224):
+    """model.py:187-437 with tf_decoder=False.  ``pos_enc_mode``:
     'center+corner_latent' | 'sinusoidal_cc' (same code path, model.py:258-271 / 288-304), 'center' | 'corner' |
-    'center+corner' (image level, model.py:203-218) or None."""
+    'center+corner' | 'dense' (image level, model.py:203-224), 'dense_latent' | 'cam_conv' (per-pixel maps resized to the 7x7
+    feature map, :244-256 / :276-288), 'pcl' | 'perspective_correction' (no encoding; the global rotation is corrected after
+    the heads, :330-334 / :370-376) or None."""
     K = meta_info["intrinsics"]
     bz = inputs["img"].shape[0]
     features = feat_vec = None
@@ -353,6 +400,9 @@ def hands_light_forward(sd, asset_r, asset_l, inputs, meta_info, img_res=224, n_
         if pos_enc_mode in ("center", "corner", "center+corner"):
             r_in = image_level_input(inputs["r_img"], inputs["r_center_angle"], inputs["r_corner_angle"], pos_enc_mode, n_freq)
             l_in = image_level_input(inputs["l_img"], inputs["l_center_angle"], inputs["l_corner_angle"], pos_enc_mode, n_freq)
+        elif pos_enc_mode == "dense":                                             # model.py:220-224
+            r_in = torch.cat([inputs["r_img"], dense_pos_enc(inputs["r_dense_angle"], inputs["r_dense_mask"], n_freq, img_res_ds)], 1)
+            l_in = torch.cat([inputs["l_img"], dense_pos_enc(inputs["l_dense_angle"], inputs["l_dense_mask"], n_freq, img_res_ds)], 1)
         else:
             r_in, l_in = inputs["r_img"], inputs["l_img"]
         r_feat = resnet50_trunk(r_in, sd, "hand_backbone_r" if separate_hands else "hand_backbone")   # model.py:226-239
@@ -361,8 +411,19 @@ def hands_light_forward(sd, asset_r, asset_l, inputs, meta_info, img_res=224, n_
             glb = features if use_glb_feat else torch.zeros_like(r_feat)          # model.py:263-267 (x + 0 == x exactly)
             r_cat = assemble_features(r_feat, glb, inputs["r_center_angle"], inputs["r_corner_angle"], n_freq)
             l_cat = assemble_features(l_feat, glb, inputs["l_center_angle"], inputs["l_corner_angle"], n_freq)
+        elif pos_enc_mode in ("dense_latent", "cam_conv"):                        # model.py:244-256 / 276-288
+            cats = []
+            for sd_, ft in (("r", r_feat), ("l", l_feat)):
+                ang, msk = inputs[f"{sd_}_dense_angle"], inputs[f"{sd_}_dense_mask"]
+                e = (dense_pos_enc(ang, msk, n_freq, img_res_ds) if pos_enc_mode == "dense_latent"
+                     else cam_conv_pos_enc(ang, msk, img_res_ds))
+                e = F.interpolate(e, size=tuple(ft.shape[2:]), mode="bilinear", align_corners=True)
+                cats.append(torch.cat([ft + features if use_glb_feat else ft, e], dim=1))
+            r_cat, l_cat = cats
         else:
             r_cat, l_cat = r_feat, l_feat            # the global features are NOT added on these routes (model.py:241-304)
+        if use_depth_loss:                                                        # model.py:308-310
+            depth_r, depth_l = depth_head(r_cat, sd), depth_head(l_cat, sd)
         r_vec = feature_conv(r_cat, sd)                                           # model.py:313
         l_vec = feature_conv(l_cat, sd)                                           # model.py:314
     hmr_r = hand_hmr(r_vec, sd, "head_r")                                         # model.py:320
@@ -370,6 +431,9 @@ def hands_light_forward(sd, asset_r, asset_l, inputs, meta_info, img_res=224, n_
 
     root_r, root_l = hmr_r["cam_t.wp"], hmr_l["cam_t.wp"]
     root_r_init, root_l_init = hmr_r["cam_t.wp.init"], hmr_l["cam_t.wp.init"]
+    if pos_enc_mode == "pcl":         # model.py:330-334: IN PLACE on the head outputs -- the flip branch and the grasp head see it
+        hmr_r["pose"][:, 0] = torch.bmm(inputs["r_rot"], hmr_r["pose"][:, 0])
+        hmr_l["pose"][:, 0] = torch.bmm(inputs["l_rot"], hmr_l["pose"][:, 0])
     pose_r, shape_r, pose_l, shape_l = hmr_r["pose"], hmr_r["shape"], hmr_l["pose"], hmr_l["shape"]
 
     flipped = meta_info["is_flipped"].bool()
@@ -393,6 +457,13 @@ def hands_light_forward(sd, asset_r, asset_l, inputs, meta_info, img_res=224, n_
         root_r_init, root_l_init = (torch.where(f1, hmr_l["cam_t.wp.init"] * sgn, root_r_init),
                                     torch.where(f1, hmr_r["cam_t.wp.init"] * sgn, root_l_init))
 
+    if pos_enc_mode == "perspective_correction":
+        # model.py:370-376, after the flip swap and IN PLACE: without a flipped sample in the batch pose_r IS the head's output
+        # tensor, so the grasp head below reads the corrected rotation; with one, torch.where made a copy and it does not
+        for pose, ang in ((pose_r, inputs["r_center_angle"]), (pose_l, inputs["l_center_angle"])):
+            rot = euler_angles_to_matrix_xyz(torch.cat([-ang, torch.zeros(bz, 1)], dim=-1))
+            pose[:, 0] = torch.matmul(rot, pose[:, 0])
+
     out = {}
     mr = mano_head(pose_r, shape_r, root_r, K, asset_r, img_res, ".r")            # model.py:378-383
     ml = mano_head(pose_l, shape_l, root_l, K, asset_l, img_res, ".l")            # model.py:385-390
@@ -405,6 +476,8 @@ def hands_light_forward(sd, asset_r, asset_l, inputs, meta_info, img_res=224, n_
         gf = feat_vec if use_glb_feat_w_grasp else None
         out["grasp.r"] = grasp_classifier(hmr_r["shape"], hmr_r["pose"], gf, sd)
         out["grasp.l"] = grasp_classifier(hmr_l["shape"], hmr_l["pose"], gf, sd)
+    if use_depth_loss:                                                            # model.py:422-424
+        out["depth.r"], out["depth.l"] = depth_r.squeeze(1), depth_l.squeeze(1)
     if regress_center_corner:                                                     # model.py:426-433
         def head3(x, p):
             for i in (0, 2):

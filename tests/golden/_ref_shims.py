@@ -66,7 +66,8 @@ _rc = _mod("pytorch3d.transforms.rotation_conversions",
            rotation_6d_to_matrix=O.rotation_6d_to_matrix,
            matrix_to_rotation_6d=O.matrix_to_rotation_6d,
            axis_angle_to_matrix=_ref_axis_angle_to_matrix,
-           matrix_to_axis_angle=ref_rot.matrix_to_axis_angle)
+           matrix_to_axis_angle=ref_rot.matrix_to_axis_angle,
+           euler_angles_to_matrix=lambda e, convention: O.euler_angles_to_matrix_xyz(e) if convention == "XYZ" else None)
 _p3d_t.rotation_conversions = _rc
 sys.modules["pytorch3d"].transforms = _p3d_t
 
@@ -104,7 +105,7 @@ class Args(dict):
 
 
 META = {"reference": "ap229997/hands @ 2024-10-22", "torch": torch.__version__,
-        "arithmetic_stubs": ["pytorch3d rotation_6d_to_matrix/matrix_to_rotation_6d -> oracle (a5 unpinned)",
+        "arithmetic_stubs": ["pytorch3d rotation_6d_to_matrix/matrix_to_rotation_6d/euler_angles_to_matrix -> oracle (a5 unpinned)",
                              "smplx.MANO -> oracle.mano_lbs on synthetic asset (a9 unpinned)"],
         "weights": "hands_amd.weights.apply_recipe", "inputs": "hands_amd.weights.synthetic_inputs"}
 TMP_DIR = _tmp

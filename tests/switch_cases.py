@@ -6,9 +6,10 @@ import numpy as np
 import torch
 
 import hands_amd
-from hands_amd.weights import synthetic_inputs
+from hands_amd.weights import synthetic_dense_inputs, synthetic_inputs
 
-SWITCH_CASES = ("arctic", "sinusoidal_cc", "center", "corner", "center_corner", "plain", "separate", "noglb")
+SWITCH_CASES = ("arctic", "sinusoidal_cc", "center", "corner", "center_corner", "plain", "separate", "noglb",
+                "dense", "dense_latent", "cam_conv", "pcl", "persp", "persp_flip", "depth")
 
 
 def load_case(golden_dir, name):
@@ -19,6 +20,8 @@ def load_case(golden_dir, name):
     args.update(meta["config"])
     inputs, meta_info = synthetic_inputs(meta["bz"], meta["seed"])
     meta_info["is_flipped"] = torch.from_numpy(d["is_flipped"])
+    if meta["config"].get("pos_enc") in ("dense", "dense_latent", "cam_conv", "pcl"):
+        inputs.update(synthetic_dense_inputs(meta["bz"], meta["seed"], meta["config"]["pos_enc"]))
     return d, meta["config"], args, inputs, meta_info
 
 
@@ -26,4 +29,4 @@ def oracle_kwargs(cfg):
     return dict(pos_enc_mode=cfg.get("pos_enc", "center+corner_latent"), no_crops=cfg.get("no_crops", False),
                 use_grasp_loss=cfg.get("use_grasp_loss", True), use_glb_feat_w_grasp=cfg.get("use_glb_feat_w_grasp", True),
                 separate_hands=cfg.get("separate_hands", False), regress_center_corner=cfg.get("regress_center_corner", False),
-                use_glb_feat=cfg.get("use_glb_feat", True))
+                use_glb_feat=cfg.get("use_glb_feat", True), use_depth_loss=cfg.get("use_depth_loss", False))

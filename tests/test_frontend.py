@@ -161,3 +161,61 @@ def test_gpu_frontend_into_hands_light():
     meta = {"intrinsics": K.to(dev), "is_flipped": torch.zeros(4, dtype=torch.int64, device=dev)}
     out = model(inputs, meta)
     assert out["mano.vertices.r"].shape == (4, 778, 3) and all(torch.isfinite(v).all() for v in out.values())
+
+
+def test_oracle_dense_maps_layout():
+    """hands_light_dataset.py:281-333 restated (numpy lines of `__getitem__`, not callable on their own): window pixels in the
+    top-left corner, first index x, zero elsewhere, mask on the window; cam_conv = angles + centred offsets + normalised coords."""
+    K = np.array([[1000.0, 0, 110.5], [0, 950.0, 120.25], [0, 0, 1]], np.float32)
+    ang, msk = F.dense_maps([30, 50, 129, 199], K, 224, cam_conv=True)
+    assert ang.shape == (6, 224, 224) and msk.shape == (224, 224) and ang.dtype == np.float32
+    assert msk[:100, :150].all() and msk.sum() == 100 * 150 and not ang[:, 100:].any() and not ang[:, :, 150:].any()
+    assert ang[0, 7, 3] == np.float32(np.arctan2(37 - np.float64(K[0, 2]), np.float64(K[0, 0])))       # x along the FIRST index
+    assert ang[1, 7, 3] == np.float32(np.arctan2(53 - np.float64(K[1, 2]), np.float64(K[1, 1])))
+    assert ang[2, 7, 3] == np.float32(37 - 110.5) and ang[3, 7, 3] == np.float32(53 - 120.25)
+    assert ang[4, 7, 3] == np.float32(2 * 37 / 224 - 1) and ang[5, 7, 3] == np.float32(2 * 53 / 224 - 1)
+    a2, m2 = F.dense_maps([30, 50, 129, 199], K, 224)
+    assert np.array_equal(a2, ang[:2]) and np.array_equal(m2, msk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pos_enc", ["dense_latent", "cam_conv"])
+def test_gpu_frontend_dense_maps_match_oracle(pos_enc):
+    from hands_amd import HandsFrontEnd
+    B = 6
+    img, jr, jl, K = _batch(B, 4)
+    fe = HandsFrontEnd({"pos_enc": pos_enc})
+    dev = torch.device("cuda:0")
+    out = fe(img.to(dev), jr.to(dev), jl.to(dev), K.to(dev))
+    torch.cuda.synchronize()
+    n = 6 if pos_enc == "cam_conv" else 2
+    for b in range(B):
+        for h in "rl":
+            ang, msk = F.dense_maps(out[f"{h}_bbox"][b].cpu().numpy(), K[b].numpy(), 224, cam_conv=pos_enc == "cam_conv")
+            got = out[f"{h}_dense_angle"][b].cpu().numpy()
+            assert got.shape == (n, 224, 224) and np.array_equal(out[f"{h}_dense_mask"][b].cpu().numpy(), msk)
+            assert np.all(np.abs(got[:2] - ang[:2]) <= np.spacing(np.abs(ang[:2])))       # double atan2 rounded to float32: <= 1 ulp
+            assert np.array_equal(got[2:], ang[2:])
+
+
+@pytest.mark.gpu
+def test_gpu_frontend_dense_into_hands_light():
+    """Front-end maps -> HandsLight(pos_enc='dense_latent') on the device == the oracle's forward on the same tensors."""
+    import hands_amd
+    from hands_amd.mano import synthetic_mano_asset
+    from oracle import hands_oracle as O
+    B = 4
+    img, jr, jl, K = _batch(B, 5)
+    args = type(hands_amd.DEFAULT_ARGS)(dict(hands_amd.DEFAULT_ARGS, pos_enc="dense_latent"))
+    dev = torch.device("cuda:0")
+    inputs = hands_amd.HandsFrontEnd(args)(img.to(dev), jr.to(dev), jl.to(dev), K.to(dev))
+    meta = {"intrinsics": K.to(dev), "is_flipped": torch.zeros(B, dtype=torch.long, device=dev)}
+    model = hands_amd.apply_recipe(hands_amd.HandsLight(args=args)).eval().to(dev)
+    out = model(inputs, meta)
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = O.hands_light_forward(sd, synthetic_mano_asset(True), synthetic_mano_asset(False),
+                                {k: v.cpu().float() if v.is_floating_point() else v.cpu() for k, v in inputs.items()},
+                                {k: v.cpu() for k, v in meta.items()}, pos_enc_mode="dense_latent")
+    for hn in "rl":
+        assert (out[f"mano.vertices.{hn}"].cpu() - ref[f"mano.vertices.{hn}"]).abs().max().item() < 1e-6

@@ -22,6 +22,7 @@ from hands_amd.mano import synthetic_mano_asset
 from hands_amd.packing import fold_bn, pack_conv, pack_linear, pack_mano
 from hands_amd.weights import synthetic_inputs
 from oracle import hands_oracle as O
+from switch_cases import SWITCH_CASES
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -712,6 +713,8 @@ def test_forward_vs_golden(golden_dir, gpu_model, bz, seed):
             np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4, err_msg=k)
         elif ".cam." in k or k.startswith("mano.cam_t."):
             np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5, err_msg=k)
+        elif k.startswith("depth."):                            # eight convolutions behind the trunk features
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4 * float(np.abs(ref).max()), err_msg=k)
         else:
             np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5, err_msg=k)
     for hn in "rl":
@@ -977,12 +980,14 @@ def test_splitk_n_is_deterministic_and_right(case):
     assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("name", ["arctic", "sinusoidal_cc", "center", "corner", "center_corner", "plain", "separate", "noglb"])
+@pytest.mark.parametrize("name", SWITCH_CASES)
 def test_switch_configurations_vs_reference_fixtures(golden_dir, name):
     """Non-default HandsLight switches through the HIP path against what the REFERENCE produced for them
     (tests/golden/make_golden_switches.py): `no_crops` (arctic_light: hands_avgpool_nhwc_f32 -> both heads), the image-level
     encodings (hands_image_posenc_nhwc_f32 -> widened conv1 on the general implicit-GEMM route + max-pool), pos_enc None,
-    'sinusoidal_cc', the grasp head without the global feature vector / absent.  Same bar as the default configuration."""
+    'sinusoidal_cc', the grasp head without the global feature vector / absent, the per-pixel encodings 'dense' / 'dense_latent' /
+    'cam_conv' (hands_dense_posenc_f32, hands_concat_nhwc_f32), the rotation corrections 'pcl' / 'perspective_correction' (with and
+    without a flipped sample) and the depth head (hands_upsample_bilinear_ac_f32).  Same bar as the default configuration."""
     from switch_cases import load_case
     d, cfg, args, inputs, meta_info = load_case(golden_dir, name)
     model = hands_amd.apply_recipe(hands_amd.HandsLight(args=args)).eval().to(DEV)
@@ -998,6 +1003,8 @@ def test_switch_configurations_vs_reference_fixtures(golden_dir, name):
             np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4, err_msg=k)
         elif ".cam." in k or k.startswith("mano.cam_t."):
             np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5, err_msg=k)
+        elif k.startswith("depth."):                            # eight convolutions behind the trunk features
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4 * float(np.abs(ref).max()), err_msg=k)
         else:
             np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5, err_msg=k)
     for hn in "rl":

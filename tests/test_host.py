@@ -156,7 +156,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()                                   # loads without a GPU
     for name in declared:
         assert hasattr(L, name), name
-    assert L.hands_abi_version() == _lib.ABI_VERSION == 2
+    assert L.hands_abi_version() == _lib.ABI_VERSION == 3
     assert L.hands_error_string(0) == b"ok" and b"invalid" in L.hands_error_string(10001)
     assert ctypes.sizeof(_lib.ConvDesc) == 16 * 4
 
@@ -256,13 +256,15 @@ def test_unsupported_switches_fail_loudly():
         hands_amd.HandsLight(args=type(hands_amd.DEFAULT_ARGS)(a))
     with pytest.raises(NotImplementedError):
         hands_amd.HandsLight(backbone="resnet18")
-    for bad in (dict(pos_enc="dense_latent"), dict(pos_enc="pcl"), dict(use_depth_loss=True), dict(use_glb_feat=False),
-                dict(regress_center_corner=True, no_crops=True)):
+    for bad in (dict(pos_enc="no_such_encoding"), dict(use_render_seg_loss=True), dict(use_depth_loss=True, no_crops=True),
+                dict(use_glb_feat=False), dict(regress_center_corner=True, no_crops=True)):
         with pytest.raises(NotImplementedError):
             hands_amd.HandsLight(args=type(hands_amd.DEFAULT_ARGS)(dict(hands_amd.DEFAULT_ARGS, **bad)))
     # built non-default switches construct (parity: tests/test_oracle_golden.py, tests/test_gpu_parity.py)
     m = hands_amd.HandsLight(args=type(hands_amd.DEFAULT_ARGS)(dict(hands_amd.DEFAULT_ARGS, pos_enc="center+corner")))
     assert m.hand_backbone.conv1.in_channels == 3 + 80 and m.feature_conv[0].in_channels == 2048
+    m = hands_amd.HandsLight(args=type(hands_amd.DEFAULT_ARGS)(dict(hands_amd.DEFAULT_ARGS, pos_enc="cam_conv", use_depth_loss=True)))
+    assert m.feature_conv[0].in_channels == 2048 + 6 and m.depth_mlp[0].in_channels == 2048 + 6 + 2 and m.depth_mlp[17].out_channels == 1
 
 
 def test_state_dict_roundtrip_and_wrapper_prefix(recipe_model):

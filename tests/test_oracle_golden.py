@@ -9,6 +9,7 @@ import torch
 from hands_amd.mano import synthetic_mano_asset
 from hands_amd.weights import synthetic_inputs
 from oracle import hands_oracle as O
+from switch_cases import SWITCH_CASES
 
 torch.set_num_threads(min(8, os.cpu_count() or 1))
 
@@ -116,7 +117,7 @@ def test_state_dict_keys_match_reference(golden_dir, recipe_model):
     assert mine == ref and len(ref) == 681
 
 
-@pytest.mark.parametrize("name", ["arctic", "sinusoidal_cc", "center", "corner", "center_corner", "plain", "separate", "noglb"])
+@pytest.mark.parametrize("name", SWITCH_CASES)
 def test_switch_configurations_match_reference(golden_dir, name):
     """Non-default HandsLight switches (model.py:40-47,60-86,127,199-232,316-318,401-411): the host mirror builds the
     reference's parameter tree for the configuration (names + shapes from the reference's own state_dict) and the oracle
@@ -135,7 +136,8 @@ def test_switch_configurations_match_reference(golden_dir, name):
     out = O.hands_light_forward(sd, synthetic_mano_asset(True), synthetic_mano_asset(False), inputs, meta_info,
                                 **oracle_kwargs(cfg))
     keys = sorted(k[4:] for k in d.files if k.startswith("out/"))
-    assert sorted(out.keys()) == keys and len(keys) == (22 if cfg.get("use_grasp_loss", True) else 20) + (4 if cfg.get("regress_center_corner") else 0)
+    assert sorted(out.keys()) == keys and len(keys) == ((22 if cfg.get("use_grasp_loss", True) else 20) + (4 if cfg.get("regress_center_corner") else 0)
+                                                     + (2 if cfg.get("use_depth_loss") else 0))
     for k in keys:
         mlp = k.startswith(("grasp", "center.", "corner."))
         tol = 1e-4 if mlp else 2e-5
