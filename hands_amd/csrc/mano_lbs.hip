@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
           for (int e = 0; e < 9; ++e) row[10 + (j - 1) * 9 + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
         }
         if (j < 10) row[j] = be[j];
-        if (j < 15) row[145 + j] = 0.f;
+        if (j < 15) row[145 + j] = j == 0 ? 1.f : 0.f;    // column 145: the constant that multiplies v_template (below)
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) {
           float acc = c.J_template[3 * j + cc];
@@ -422,10 +422,11 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
       if (tt > 0 && ch == NCHUNK - 1) break;           // chunk 12 holds vertices in its first two row tiles only (2304 ... 2335)
       int m0 = ch * CHUNK_M + (wave + 4 * tt) * 16;
       m0 = m0 < 2432 ? m0 : 2432 - 16;
-      const float4 bias = *reinterpret_cast<const float4*>(S.blend_bias + m0 + 4 * g);
+      // v_template is column 145 of the packed matrix (hands_pack_mano_f32) against the constant 1 of the input row: the
+      // accumulators start at zero and no tile waits for a bias load before its first MFMA
       f32x4 acc[MH / 16];
 #pragma unroll
-      for (int nt = 0; nt < MH / 16; ++nt) { acc[nt][0] = bias.x; acc[nt][1] = bias.y; acc[nt][2] = bias.z; acc[nt][3] = bias.w; }
+      for (int nt = 0; nt < MH / 16; ++nt) { acc[nt][0] = 0.f; acc[nt][1] = 0.f; acc[nt][2] = 0.f; acc[nt][3] = 0.f; }
       float4 wn[10];                                   // next tile's fragments, requested under this tile's MFMAs
       if (tt < 2) {
         int m1 = ch * CHUNK_M + (wave + 4 * (tt + 1)) * 16;
@@ -438,9 +439,9 @@ __global__ void __launch_bounds__(256, 2) mano_heads_kernel(ManoHeadsArgs a) {
       for (int s4 = 0; s4 < 10; ++s4) {
 #pragma unroll
         for (int nt = 0; nt < MH / 16; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s4].x, bfrag[nt][s4].x, acc[nt], 0, 0, 0);
-        if (s4 == 9) continue;       // .y .z .w of the last step are k = 145 ... 159: the zero padding of the input row
 #pragma unroll
         for (int nt = 0; nt < MH / 16; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s4].y, bfrag[nt][s4].y, acc[nt], 0, 0, 0);
+        if (s4 == 9) continue;       // .y of the last step is k = 145 (1 x v_template), .z .w are k = 146 ... 159: zero padding
 #pragma unroll
         for (int nt = 0; nt < MH / 16; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s4].z, bfrag[nt][s4].z, acc[nt], 0, 0, 0);
 #pragma unroll

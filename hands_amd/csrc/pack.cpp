@@ -141,6 +141,7 @@ int hands_pack_mano_f32(const float* v_template, const float* shapedirs, const f
     for (int k = 0; k < NB; ++k) row[k] = shapedirs[m * NB + k];
     for (int p = 0; p < NP; ++p) row[NB + p] = posedirs[(size_t)p * M + m];
     blend_bias_packed[m] = v_template[m];
+    row[NB + NP] = v_template[m];      // column 145: see include/hands_hip.h
   }
   return 0;
 }

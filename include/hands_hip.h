@@ -539,6 +539,10 @@ int hands_pack_linear_f64(int N, int K, const double* w, const double* bias, con
                           float* bias_packed);
 int hands_pack_conv1x1_dual_f64(int Cout, int K0, int K1, const double* w0, const double* b0,
                                 const double* w1, const double* b1, float* w_packed, float* bias_packed);
+/* blend_w_packed (2432, 160): row m = [shapedirs[m, 0..9] | posedirs[0..134, m] | v_template[m] | 14 zeros], rows 2334.. zero;
+ * blend_bias_packed (2432) = v_template.  hands_mano_heads_f32 multiplies column 145 with a constant 1 in its input rows (its
+ * accumulators start at zero: no bias load in front of a tile); the three-launch chain (hands_mano_pose_f32 -> GEMM ->
+ * hands_mano_skin_f32) writes 0 there and adds blend_bias_packed in the GEMM epilogue. */
 int hands_pack_mano_f32(const float* v_template, const float* shapedirs, const float* posedirs,
                         const float* J_regressor, const float* hands_mean, float* pose_mean,
                         float* J_template, float* J_shapedirs, float* blend_w_packed,

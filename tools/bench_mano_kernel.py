@@ -11,7 +11,9 @@ from hands_amd.packing import pack_mano
 
 dev = torch.device("cuda:0")
 L = _lib.lib()
-for bz in (128, 256, 1024, 4096):
+SIZES = tuple(int(v) for v in sys.argv[1].split(",")) if len(sys.argv) > 1 else (128, 256, 1024, 4096)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 200      # (PMC passes: few launches, e.g. "4096 5")
+for bz in SIZES:
     mps = [pack_mano(hands_amd.synthetic_mano_asset(s), dev) for s in (True, False)]
     g = torch.Generator().manual_seed(0)
     q, _ = torch.linalg.qr(torch.randn(2 * bz * 16, 3, 3, generator=g))
@@ -28,10 +30,9 @@ for bz in (128, 256, 1024, 4096):
         sides[s] = ManoSide(c, ptr(mp["blend"].w), ptr(mp["blend"].bias), ptr(rot, s * bz * 144), ptr(betas, s * bz * 10),
                             ptr(cam, s * bz * 3), ManoOut(*[ptr(t) for t in o]))
     st = torch.cuda.current_stream().cuda_stream
-    for _ in range(20):
+    for _ in range(min(20, N)):
         check(L.hands_mano_heads_f32(sides, 2, ptr(K), 10, 224.0, 0.1, bz, 0, st))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    N = 200
     e0.record()
     for _ in range(N):
         check(L.hands_mano_heads_f32(sides, 2, ptr(K), 10, 224.0, 0.1, bz, 0, st))
