@@ -186,7 +186,9 @@ class HAMER(EngineSwitches, nn.Module):
         get = args.get if hasattr(args, "get") else (lambda k, d=None: getattr(args, k, d))
         self.args = args
         # built: pos_enc 'center+corner_latent' (shipped) or None (no KPE: model.py:91-97,102-104), grasp head on or off
-        # (model.py:59-72,136-143); 'dense_latent' (dense angle maps) and the renderer are not
+        # (model.py:59-72,136-143).  'dense_latent' cannot run in the reference either: PositionalEncoding.forward calls
+        # compute_dense_pos_enc(angle, mask) without its `size` argument (hamer_light/pos_emb.py:41 vs :66) -> TypeError.  The
+        # renderer is not built
         if get("pos_enc") not in ("center+corner_latent", None) or get("use_render_seg_loss", False):
             raise NotImplementedError("hands_amd.HAMER: pos_enc must be 'center+corner_latent' or None, renderer off")
         self.n_freq = int(get("n_freq_pos_enc", 4))

@@ -65,7 +65,9 @@ class HandOccNet(EngineSwitches, nn.Module):
         args = args if args is not None else HANDOCC_DEFAULT_ARGS
         get = args.get if hasattr(args, "get") else (lambda k, d=None: getattr(args, k, d))
         self.args = args
-        # built: pos_enc 'center+corner_latent' (shipped) or None (model.py:74-89: no KPE anywhere), grasp head on or off
+        # built: pos_enc 'center+corner_latent' (shipped) or None (model.py:74-89: no KPE anywhere), grasp head on or off;
+        # 'dense_latent' fails in the reference's own PositionalEncoding (hamer_light/pos_emb.py:41 calls compute_dense_pos_enc
+        # without its `size` argument)
         if get("pos_enc") not in ("center+corner_latent", None) or get("use_render_seg_loss", False):
             raise NotImplementedError("hands_amd.HandOccNet: pos_enc must be 'center+corner_latent' or None, renderer off")
         self.n_freq = int(get("n_freq_pos_enc", 4))
