@@ -81,16 +81,26 @@ __global__ void frontend_boxes_kernel(BoxArgs a) {
   }
   // KPE angles of the crop window (center: float64 atan2 stored as float32)
   {
-    const float* K = a.K + 9 * b;
-    const double fx = K[0], fy = K[4], px = K[2], py = K[5];
+    // K == NULL: args.no_intrx (hands_light_dataset.py:247-253): the encodings use the float64 stand-in
+    // [[res/2, 0, res/2], [0, res/2, res/2], [0, 0, 1]] instead of the camera's intrinsics
+    const float* K = a.K ? a.K + 9 * b : nullptr;
+    const double half = a.img_res / 2.0;
+    const double fx = K ? (double)K[0] : half, fy = K ? (double)K[4] : half, px = K ? (double)K[2] : half, py = K ? (double)K[5] : half;
     const double bx0 = nb[0], by0 = nb[1], bx1 = nb[2], by1 = nb[3];
     float* c = a.center[hand] + 2 * b;
     c[0] = (float)atan2((bx0 + bx1) / 2.0 - px, fx);
     c[1] = (float)atan2((by0 + by1) / 2.0 - py, fy);
     float* q = a.corner[hand] + 8 * b;
-    // corners: numpy keeps int16 - float32 in float32, so the reference evaluates these in float32
-    const float ax0 = atan2f((float)nb[0] - K[2], K[0]), ax1 = atan2f((float)nb[2] - K[2], K[0]);
-    const float ay0 = atan2f((float)nb[1] - K[5], K[4]), ay1 = atan2f((float)nb[3] - K[5], K[4]);
+    float ax0, ax1, ay0, ay1;
+    if (K) {
+      // corners: numpy keeps int16 - float32 in float32, so the reference evaluates these in float32
+      ax0 = atan2f((float)nb[0] - K[2], K[0]); ax1 = atan2f((float)nb[2] - K[2], K[0]);
+      ay0 = atan2f((float)nb[1] - K[5], K[4]); ay1 = atan2f((float)nb[3] - K[5], K[4]);
+    } else {
+      // int16 - float64 is float64: double atan2, rounded once
+      ax0 = (float)atan2(bx0 - px, fx); ax1 = (float)atan2(bx1 - px, fx);
+      ay0 = (float)atan2(by0 - py, fy); ay1 = (float)atan2(by1 - py, fy);
+    }
     q[0] = ax0; q[1] = ay0; q[2] = ax0; q[3] = ay1; q[4] = ax1; q[5] = ay0; q[6] = ax1; q[7] = ay1;
   }
 }
@@ -194,12 +204,13 @@ __global__ void dense_maps_kernel(const int32_t* __restrict__ bbox, const float*
   const int i = p / R, j = p - i * R;
   const int x0 = bbox[b * 4], y0 = bbox[b * 4 + 1], x1 = bbox[b * 4 + 2], y1 = bbox[b * 4 + 3];
   const bool in = i <= x1 - x0 && j <= y1 - y0;
-  const float* Kb = K + b * 9;
+  const float* Kb = K ? K + b * 9 : nullptr;             // NULL: args.no_intrx, as in frontend_boxes_kernel
+  const double half = R / 2.0;
   float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (in) {
-    const double dx = (double)(x0 + i) - (double)Kb[2], dy = (double)(y0 + j) - (double)Kb[5];
-    v[0] = (float)atan2(dx, (double)Kb[0]);
-    v[1] = (float)atan2(dy, (double)Kb[4]);
+    const double dx = (double)(x0 + i) - (Kb ? (double)Kb[2] : half), dy = (double)(y0 + j) - (Kb ? (double)Kb[5] : half);
+    v[0] = (float)atan2(dx, Kb ? (double)Kb[0] : half);
+    v[1] = (float)atan2(dy, Kb ? (double)Kb[4] : half);
     v[2] = (float)dx;
     v[3] = (float)dy;
     v[4] = (float)(2.0 * (double)(x0 + i) / (double)R - 1.0);
@@ -213,7 +224,7 @@ __global__ void dense_maps_kernel(const int32_t* __restrict__ bbox, const float*
 
 extern "C" int hands_frontend_dense_maps_f32(const int32_t* bbox, const float* K, float* angle, float* mask, int B, int img_res,
                                              int nch, hands_stream_t stream) {
-  if (!bbox || !K || !angle || !mask || B <= 0 || B > 65535 || img_res < 1 || (nch != 2 && nch != 6)) return HANDS_EINVAL;
+  if (!bbox || !angle || !mask || B <= 0 || B > 65535 || img_res < 1 || (nch != 2 && nch != 6)) return HANDS_EINVAL;   // K may be NULL
   hipLaunchKernelGGL(dense_maps_kernel, dim3((img_res * img_res + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, bbox, K, angle,
                      mask, B, img_res, nch);
   HANDS_LAUNCH_CHECK();
@@ -224,7 +235,7 @@ extern "C" int hands_frontend_boxes_f32(const float* j2d_r, const float* j2d_l, 
                                         int32_t* bbox_r, int32_t* bbox_l, int32_t* bbox_og_r, int32_t* bbox_og_l,
                                         float* trans_r, float* trans_l, float* center_r, float* center_l,
                                         float* corner_r, float* corner_l, hands_stream_t stream) {
-  if (!j2d_r || !j2d_l || !K || !bbox_r || !bbox_l || !bbox_og_r || !bbox_og_l || !trans_r || !trans_l ||
+  if (!j2d_r || !j2d_l || !bbox_r || !bbox_l || !bbox_og_r || !bbox_og_l || !trans_r || !trans_l ||
       !center_r || !center_l || !corner_r || !corner_l)
     return HANDS_EINVAL;
   if (B <= 0 || ld < 2 || img_res < 2 || out_res < 1 || !(bbox_scale > 0.0)) return HANDS_EINVAL;

@@ -35,8 +35,7 @@ class HandsFrontEnd:
         pos_enc = g("pos_enc", "center+corner_latent")
         # per-pixel maps of the crop windows (hands_light_dataset.py:281-333): 2 angle maps, or 6 maps for 'cam_conv'
         self.dense_channels = 0 if pos_enc is None else 6 if "cam_conv" in pos_enc else 2 if "dense" in pos_enc else 0
-        if g("no_intrx", False):
-            raise NotImplementedError("no_intrx front-end variant is not built (configs/hands_light.py:29 default False)")
+        self.no_intrx = bool(g("no_intrx", False))      # hands_light_dataset.py:247-253: encodings from f = c = img_res / 2
 
     def boxes(self, joints2d_r, joints2d_l, intrinsics):
         """-> dict with {r,l}_bbox (B,4) int16 [x0,y0,x1,y1], {r,l}_bbox_og, {r,l}_trans (B,6), angles."""
@@ -54,7 +53,8 @@ class HandsFrontEnd:
             o[f"{h}_trans"] = torch.empty(B, 6, device=dev)
             o[f"{h}_center_angle"] = torch.empty(B, 2, device=dev)
             o[f"{h}_corner_angle"] = torch.empty(B, 8, device=dev)
-        check(L.hands_frontend_boxes_f32(ptr(jr), ptr(jl), ld, ptr(K), B, self.img_res, self.img_res_ds, self.bbox_scale,
+        Kenc = None if self.no_intrx else ptr(K)
+        check(L.hands_frontend_boxes_f32(ptr(jr), ptr(jl), ld, Kenc, B, self.img_res, self.img_res_ds, self.bbox_scale,
                                          ptr(o["r_bbox"]), ptr(o["l_bbox"]), ptr(o["r_bbox_og"]), ptr(o["l_bbox_og"]),
                                          ptr(o["r_trans"]), ptr(o["l_trans"]), ptr(o["r_center_angle"]), ptr(o["l_center_angle"]),
                                          ptr(o["r_corner_angle"]), ptr(o["l_corner_angle"]),
@@ -64,7 +64,7 @@ class HandsFrontEnd:
             for h in "rl":
                 o[f"{h}_dense_angle"] = torch.empty(B, n, R, R, device=dev)
                 o[f"{h}_dense_mask"] = torch.empty(B, R, R, device=dev)
-                check(L.hands_frontend_dense_maps_f32(ptr(o[f"{h}_bbox"]), ptr(K), ptr(o[f"{h}_dense_angle"]), ptr(o[f"{h}_dense_mask"]),
+                check(L.hands_frontend_dense_maps_f32(ptr(o[f"{h}_bbox"]), Kenc, ptr(o[f"{h}_dense_angle"]), ptr(o[f"{h}_dense_mask"]),
                                                       B, R, n, torch.cuda.current_stream(dev).cuda_stream), "hands_frontend_dense_maps_f32")
         for k in ("r_bbox", "l_bbox", "r_bbox_og", "l_bbox_og"):
             o[k] = o[k].to(torch.int16)                                   # the reference's dtype (astype(np.int16))

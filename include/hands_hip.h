@@ -478,7 +478,9 @@ int hands_unnormalize_kp2d_f32(const float* x, float* out, long long n, float im
  *                                                  (src/datasets/hands_light_dataset.py:137-152);
  *   crop window [x0,y0,x1,y1] of crop_and_pad (common/data_utils.py:495-509; an empty box -> whole image);
  *   the float32 2x3 affine gen_trans_from_patch_cv builds for it (common/data_utils.py:56-91, rot=0);
- *   center (2) / corner (8) angles atan2(p - c, f) of the window (hands_light_dataset.py:256-279).
+ *   center (2) / corner (8) angles atan2(p - c, f) of the window (hands_light_dataset.py:256-279); K == NULL: args.no_intrx
+ *   (hands_light_dataset.py:247-253) -- the encodings use f = c = img_res / 2 (a float64 matrix: the corner angles are then
+ *   evaluated in double like the center angles) instead of the camera's intrinsics; hands_frontend_dense_maps_f32 likewise.
  *   bbox_og = the box itself, or [0,0,res-1,res-1] when empty (hands_light_dataset.py:145-152).
  * hands_warp_affine_cubic_norm_f32: cv2.warpAffine(src, trans, (Wo,Ho), INTER_CUBIC) with constant-0
  *   border (generate_patch_image_clean, common/data_utils.py:423-460), then clip to [0,1] and

@@ -205,13 +205,20 @@ def kpe_angles(bbox_xyxy, K):
     int16 - float32 = float32, so the corner atan2 runs in float32 -- as the reference's numpy does
     with the float32 intrinsics of `get_wp_intrix` (common/data_utils.py:376-385)."""
     b = np.asarray(bbox_xyxy)
-    K = np.asarray(K)
+    K = np.asarray(K)      # float32 intrinsics, or the float64 stand-in of no_intrx_matrix() (then everything below is float64)
     center = (b[:2] + b[2:]) / 2.0
     center_angle = np.array([np.arctan2(center[0] - K[0, 2], K[0, 0]), np.arctan2(center[1] - K[1, 2], K[1, 1])]).astype(np.float32)
     corner = np.array([[b[0], b[1]], [b[0], b[3]], [b[2], b[1]], [b[2], b[3]]])
     corner = np.stack([corner[:, 0] - K[0, 2], corner[:, 1] - K[1, 2]], axis=-1)
     corner_angle = np.arctan2(corner, np.array([[K[0, 0], K[1, 1]]])).flatten().astype(np.float32)
     return center_angle, corner_angle
+
+
+def no_intrx_matrix(img_res=224):
+    """hands_light_dataset.py:247-253 (args.no_intrx): np.eye(3) with f = c = img_res / 2 -- float64."""
+    K = np.eye(3)
+    K[0, 0] = K[1, 1] = K[0, 2] = K[1, 2] = img_res / 2
+    return K
 
 
 def dense_maps(bbox_xyxy, K, img_res=224, cam_conv=False):

@@ -219,3 +219,28 @@ def test_gpu_frontend_dense_into_hands_light():
                                 {k: v.cpu() for k, v in meta.items()}, pos_enc_mode="dense_latent")
     for hn in "rl":
         assert (out[f"mano.vertices.{hn}"].cpu() - ref[f"mano.vertices.{hn}"]).abs().max().item() < 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_frontend_no_intrx_matches_oracle():
+    """args.no_intrx (hands_light_dataset.py:247-253): the encodings come from the float64 stand-in intrinsics f = c = img_res / 2;
+    boxes, crops and the intrinsics handed to the model do not change."""
+    from hands_amd import HandsFrontEnd
+    B = 6
+    img, jr, jl, K = _batch(B, 6)
+    dev = torch.device("cuda:0")
+    base = HandsFrontEnd({"pos_enc": "cam_conv"})(img.to(dev), jr.to(dev), jl.to(dev), K.to(dev))
+    out = HandsFrontEnd({"pos_enc": "cam_conv", "no_intrx": True})(img.to(dev), jr.to(dev), jl.to(dev), K.to(dev))
+    torch.cuda.synchronize()
+    Kn = F.no_intrx_matrix(224)
+    for b in range(B):
+        for h in "rl":
+            bbox = out[f"{h}_bbox"][b].cpu().numpy()
+            assert np.array_equal(bbox, base[f"{h}_bbox"][b].cpu().numpy()) and torch.equal(out[f"{h}_img"][b], base[f"{h}_img"][b])
+            ce, co = F.kpe_angles(bbox, Kn)
+            for got, ref in ((out[f"{h}_center_angle"][b], ce), (out[f"{h}_corner_angle"][b], co)):
+                assert np.all(np.abs(got.cpu().numpy() - ref) <= np.spacing(np.abs(ref)).astype(np.float32))     # double atan2: <= 1 ulp
+            ang, msk = F.dense_maps(bbox, Kn, 224, cam_conv=True)
+            got = out[f"{h}_dense_angle"][b].cpu().numpy()
+            assert np.all(np.abs(got[:2] - ang[:2]) <= np.spacing(np.abs(ang[:2]))) and np.array_equal(got[2:], ang[2:])
+    assert not torch.equal(out["r_corner_angle"], base["r_corner_angle"])
