@@ -112,10 +112,12 @@ def pack_mano(asset: ManoAsset, device):
     J_template = (Jr @ vt).astype(np.float32)            # (16,3)
     J_shapedirs = np.einsum("jv,vck->jck", Jr, sd).reshape(48, 10).astype(np.float32)
     pose_mean = np.concatenate([np.zeros(3, np.float32), asset.hands_mean.astype(np.float32)])
-    # blend matrix as a Linear weight (N=2334 outputs, K=145 inputs [beta | pose_feature])
-    Wb = np.concatenate([sd.reshape(-1, 10), asset.posedirs.astype(np.float64).T], axis=1)  # (2334,145)
+    # blend matrix as a Linear weight (N=2334 outputs, K=146 inputs [beta | pose_feature | 1]): column 145 is v_template, which
+    # hands_mano_heads_f32 multiplies with a constant 1 (include/hands_hip.h); the bias vector serves the three-launch chain
+    Wb = np.concatenate([sd.reshape(-1, 10), asset.posedirs.astype(np.float64).T, vt.reshape(-1, 1)], axis=1)  # (2334,146)
     blend = pack_linear(torch.from_numpy(Wb), torch.from_numpy(vt.reshape(-1)), device,
-                        k_total=145, n_total=2336)
+                        k_total=146, n_total=2336)
+    blend.macs_per_pixel = 2334 * 145                   # the algorithmic contraction (the template column is the bias)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     return {
         "pose_mean": t(pose_mean), "J_template": t(J_template), "J_shapedirs": t(J_shapedirs),
