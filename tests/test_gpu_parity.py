@@ -1015,3 +1015,21 @@ def test_switch_configurations_vs_reference_fixtures(golden_dir, name):
     one = model({k: v[1:].contiguous() for k, v in dev(inputs).items()}, {k: v[1:].contiguous() for k, v in dev(meta_info).items()})
     for k in keys:
         assert torch.equal(one[k], out[k][1:]), k
+
+
+def test_depth_head_passes_are_batch_independent():
+    """use_depth_loss at 130 samples: the depth head walks its 260 crops in passes of 256 (the 224 x 224 x 32 map of one pass is
+    1.6 GB); samples of the first and of the second pass equal the same samples run as a pair, bit for bit."""
+    args = type(hands_amd.DEFAULT_ARGS)(dict(hands_amd.DEFAULT_ARGS, use_depth_loss=True))
+    model = hands_amd.apply_recipe(hands_amd.HandsLight(args=args)).eval().to(DEV)
+    inputs, meta = synthetic_inputs(130, 9)
+    dev = lambda t: {k: v.to(DEV) for k, v in t.items()}
+    inputs, meta = dev(inputs), dev(meta)
+    big = model(inputs, meta)
+    big = {k: v.clone() for k, v in big.items()}
+    assert big["depth.r"].shape == (130, 224, 224) and torch.isfinite(big["depth.l"]).all()
+    for lo in (0, 128):
+        cut = lambda t: {k: v[lo:lo + 2].contiguous() for k, v in t.items()}
+        small = model(cut(inputs), cut(meta))
+        for k in ("depth.r", "depth.l", "mano.vertices.r", "mano.vertices.l", "grasp.l"):
+            assert torch.equal(small[k], big[k][lo:lo + 2]), (k, lo)
