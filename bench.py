@@ -32,6 +32,7 @@ doubles as the parity checker (``parity``: that sample + a multi-seed sweep).
 import argparse
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -956,13 +957,14 @@ def main():
         # *_winograd_all: HandOccNet's opt-in scope
         for name, abz, asteps, awarm, pbz in (("hands_light_bf16x3", 256, 10, 3, 8), ("hamer_light", 64, 4, 1, 1),
                                               ("hamer_light_bf16x3", 64, 4, 1, 1), ("handoccnet_light", 32, 10, 3, 2),
-                                              ("handoccnet_light_graph2", 32, 10, 3, 2),
+                                              ("handoccnet_light_graph4", 32, 12, 4, 2),
                                               ("handoccnet_light_winograd_all", 32, 10, 3, 2)):
             key = name
             try:
                 math, wino, wscope, graph = "fp32", None, None, 0
-                if name.endswith("_graph2"):        # hands_amd.GraphedForward(depth=2): two captured forwards in flight
-                    name, graph = name[: -len("_graph2")], 2
+                mg = re.search(r"_graph(\d+)$", name)   # hands_amd.GraphedForward(depth=N): N captured forwards in flight
+                if mg:                                   # (depth 2 / 3 / 4 / 6 measured 3617 / 3670 / 3703 / 3752 hands/s, eager 3657)
+                    name, graph = name[: mg.start()], int(mg.group(1))
                 if name.endswith("_winograd_all"):
                     name, wino, wscope = name[: -len("_winograd_all")], True, "all"
                 if name.endswith("_bf16x3"):
