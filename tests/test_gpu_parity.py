@@ -1033,3 +1033,30 @@ def test_depth_head_passes_are_batch_independent():
         small = model(cut(inputs), cut(meta))
         for k in ("depth.r", "depth.l", "mano.vertices.r", "mano.vertices.l", "grasp.l"):
             assert torch.equal(small[k], big[k][lo:lo + 2]), (k, lo)
+
+
+@pytest.mark.parametrize("over", [dict(pos_enc="dense_latent"), dict(pos_enc="pcl"), dict(use_depth_loss=True)])
+def test_graphed_forward_of_non_default_configurations(over):
+    """hipGraph replay of configurations with extra inputs (per-pixel maps, the pcl rotations) and extra kernels (the depth head):
+    the replay on new inputs equals the eager forward bit for bit."""
+    from hands_amd import GraphedForward
+    from hands_amd.weights import synthetic_dense_inputs
+    args = type(hands_amd.DEFAULT_ARGS)(dict(hands_amd.DEFAULT_ARGS, **over))
+    model = hands_amd.apply_recipe(hands_amd.HandsLight(args=args)).eval().to(DEV)
+
+    def batch(seed):
+        inputs, meta = synthetic_inputs(2, seed)
+        if over.get("pos_enc") in ("dense_latent", "pcl"):
+            inputs.update(synthetic_dense_inputs(2, seed, over["pos_enc"]))
+        meta["is_flipped"] = torch.tensor([seed & 1, 0])
+        return {k: v.to(DEV) for k, v in inputs.items()}, {k: v.to(DEV) for k, v in meta.items()}
+
+    gf = GraphedForward(model, *batch(0))
+    for seed in (1, 2):
+        inputs, meta = batch(seed)
+        want = {k: v.clone() for k, v in model(inputs, meta).items()}
+        got = gf(inputs, meta)
+        torch.cuda.synchronize()
+        assert sorted(got.keys()) == sorted(want.keys())
+        for k in want:
+            assert torch.equal(got[k], want[k]), (over, seed, k)
