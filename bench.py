@@ -425,8 +425,9 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
     elapsed = ctx.timed(step, steps, warmup)
     enqueue_ms = host_enqueue_ms(ctx, step)
     rank_rates = ctx.gather_floats(2 * bz * steps / ctx.last_local_seconds)
-    gather_us = allgather_us(ctx, lambda: model(inputs, meta)) if ctx.world > 1 and not ctx.host_collective else None
-    d2h_ms = forward_with_d2h_ms(ctx, model, inputs, meta, max(2, min(steps, 5))) if ctx.world == 1 else None
+    # (both through `fwd`, the execution mode `value` was measured in: the hipGraph replay when --graph is set)
+    gather_us = allgather_us(ctx, lambda: fwd(inputs, meta)) if ctx.world > 1 and not ctx.host_collective else None
+    d2h_ms = forward_with_d2h_ms(ctx, fwd, inputs, meta, max(2, min(steps, 5))) if ctx.world == 1 else None
     if ctx.rank != 0:
         return None, model, None
     flop_per_hand = FLOP_PER_HAND[workload]

@@ -440,8 +440,9 @@ static bool wino_sizes_ok(const hands_conv_desc* d) {
 
 static bool wino_ok(const hands_conv_desc* d) {
   const int act = d->act & HANDS_ACT_MASK;
-  return wino_sizes_ok(d) && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->H && d->Wo == d->W && d->B > 0 && d->H > 0 &&
-         d->W > 0 && d->Cin >= 16 && d->Cin % 16 == 0 && d->Cout >= 32 && d->Cout % 32 == 0 && d->in_pix_stride >= d->Cin &&
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0) return false;       // before wino_sizes_ok(): it divides by the tile-row count
+  return wino_sizes_ok(d) && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->H && d->Wo == d->W &&
+         d->Cin >= 16 && d->Cin % 16 == 0 && d->Cout >= 32 && d->Cout % 32 == 0 && d->in_pix_stride >= d->Cin &&
          d->out_pix_stride >= d->Cout && d->in_pix_stride % 4 == 0 && d->out_pix_stride % 4 == 0 &&
          (act == HANDS_ACT_NONE || act == HANDS_ACT_RELU || act == HANDS_ACT_LEAKY_RELU) && !(d->act & HANDS_MATH_BF16X3);
 }

@@ -232,6 +232,14 @@ constexpr int CHUNK_M = 192;       // blend outputs per chunk = 12 row tiles of 
 constexpr int NCHUNK = (NV + CHUNK_V - 1) / CHUNK_V;   // 13
 constexpr int VROW = 196;          // LDS row of the v_posed stage (49 x 16 B: odd)
 constexpr int BROW = 164;          // LDS row of the blend input (41 x 16 B: odd)
+// geometry the blend loop's two shortcuts rely on (mano_heads_kernel): the last chunk's 3 * (778 - 12 * 64) = 30 outputs fit row
+// tiles 0-1 (tile tt > 0 of a wave is skipped there), and the contraction is 10 shape + 135 pose + 1 (v_template) = 146 of the
+// packed row's 160 columns, so the last k-step of four holds k = 144, 145 in .x .y and zero padding in .z .w
+constexpr int BLEND_K = 10 + 135 + 1, BLEND_KPAD = 160;
+static_assert(3 * (NV - (NCHUNK - 1) * CHUNK_V) <= 32, "last chunk must fit the first two 16-row tiles");
+static_assert(BLEND_K == 146 && BLEND_KPAD == 160 && BLEND_KPAD - BLEND_K >= 14 && (BLEND_K - 1) / 16 == 9 && (BLEND_K - 1) % 16 < 4 * 4,
+              "k = 145 must be the last non-zero column, in the last of ten 16-wide steps");
+static_assert(CHUNK_M == 3 * CHUNK_V && CHUNK_M == 12 * 16, "a chunk is 12 row tiles of 16 outputs");
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -41,6 +41,13 @@ class ConvEngine:
         self.fuse_mano = True         # MANOHead.forward of both hands as one launch (hands_mano_heads_f32)
         self.fuse_pre = True          # handoccnet_light's pre-activation units: BatchNorm -> LeakyReLU folded into the operand
                                       # staging of the unit's first (pointwise) convolution (hands_conv2d_nhwc_pre_f32)
+        self.chain_limit = 0          # > 0: blocked fp32 summation.  A direct (non-Winograd) launch whose contraction is at least
+                                      # chain_min_k floats long is cut into S = Kpad / chain_limit K-slices by the deterministic
+                                      # split-K form (partial sums added in slice order), so no fp32 FMA chain is longer than
+                                      # chain_limit floats: fewer roundings per output, at a workspace round trip per such launch.
+                                      # A fixed function of the layer -- batch-size independent.  HandOccNet sets it (DESIGN.md
+                                      # "Conditioning note"); 0 elsewhere
+        self.chain_min_k = 0          # launches with Kpad below max(chain_min_k, 2 * chain_limit) keep their single chain
         self.hook = None              # callable(phase, pc, npix, stream_handle, has_res, kernel): bench.py brackets
                                       # every MFMA launch (conv_igemm and the fused stem) with events; `kernel` is the
                                       # kernel the launch really runs (conv_igemm_f32_kernel / conv_igemm_sk_f32_kernel =
@@ -48,20 +55,37 @@ class ConvEngine:
         self.last_wino_macs = 0       # executed (not algorithmic) MACs of the Winograd launch the hook is being called for
         self._splitk_ws = {}          # (device, stream handle) -> workspace tensor
         self._sk_ws = {}              # (device, stream handle) -> [zeroed stream-K workspace, epoch counter]
-        self._capture_ws = {}         # split-K workspaces of launches recorded into a hipGraph (graph memory pool)
+        self._capture_ws = {}         # split-K workspaces of launches recorded into the hipGraph being captured (graph memory
+                                      # pool): the table of the CURRENT capture, see begin_capture()
+        self._capture_tables = {}     # capture token -> its table (kept alive as long as the captured graph may replay)
+        self._capture_seq = 0
 
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
-        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "winograd", "fuse_mano", "fuse_pre", "stream_k", "math"):
+        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "winograd", "fuse_mano", "fuse_pre", "stream_k", "math", "chain_limit",
+                  "chain_min_k"):
             setattr(e, k, getattr(self, k))
         return e
+
+    def begin_capture(self) -> int:
+        """A hipGraph capture is about to record launches of this engine: give it a workspace table of its own and return
+        its token.  Other live captures of the same (possibly shared) engine keep theirs."""
+        self._capture_seq += 1
+        self._capture_ws = self._capture_tables[self._capture_seq] = {}
+        return self._capture_seq
+
+    def drop_capture(self, token: int):
+        """The graph captured under ``token`` will not be replayed again."""
+        t = self._capture_tables.pop(token, None)
+        if t is not None and t is self._capture_ws:
+            self._capture_ws = {}
 
     def release_workspaces(self, dev=None):
         """Drop the per-stream split-K / stream-K workspaces (all devices, or one).  They are keyed by the raw
         stream handle the launch went to: a model calls this when it drops its side streams (``invalidate_packed``,
         ``.to()``), so a later stream that happens to get a recycled handle starts from a fresh, zero-filled
         workspace and no destroyed stream keeps 64 MB pinned."""
-        for table in (self._splitk_ws, self._sk_ws, self._capture_ws):
+        for table in (self._splitk_ws, self._sk_ws, self._capture_ws, *self._capture_tables.values()):
             for key in [k for k in table if dev is None or k[0] == dev]:
                 del table[key]
 
@@ -124,6 +148,10 @@ class ConvEngine:
             if hook is not None:
                 hook("end", pc, B * Ho * Wo, stream, False, "conv_wino_f32_kernel")
             return Ho, Wo
+        if (self.chain_limit and self.use_splitk and self.math == "fp32"
+                and pc.Kpad >= max(2 * self.chain_limit, self.chain_min_k)):
+            # blocked summation (not the Winograd launches above: their chains are Cin long)
+            S = max(S, min(pc.Kpad // self.chain_limit, 32))
         if pre is not None:
             # pointwise layer behind an eval BatchNorm -> LeakyReLU (pre = (scale, shift) device vectors): the affine +
             # activation is applied to the operand on its way into LDS (hands_conv2d_nhwc_pre_f32)

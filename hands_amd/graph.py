@@ -37,6 +37,7 @@ class GraphedForward:
         own = lambda d: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in d.items()}
         self.model, self.dev, self.depth = model, dev, int(depth)
         self._calls = 0
+        self._tokens = []
         self.static_in, self.static_meta, self.static_out, self.graphs = [], [], [], []
         self._done = [None] * self.depth          # event of the last replay of instance i (pipelined mode)
         self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.depth)] if self.depth > 1 else []
@@ -50,8 +51,8 @@ class GraphedForward:
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             eng = getattr(model, "engine", None)
-            if eng is not None:
-                eng._capture_ws = {}              # split-K workspaces of THIS capture come from its own memory pool
+            if eng is not None:                   # split-K workspaces of THIS capture come from its own memory pool; the tables
+                self._tokens.append((eng, eng.begin_capture()))     # of other live captures on a shared engine stay
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = model(s_in, s_meta)
@@ -74,10 +75,10 @@ class GraphedForward:
         clone what must survive the next ``depth`` calls.  depth > 1: the result is a `stream_xdict` joined at
         its first use; the caller may overwrite its inputs as soon as this returns."""
         i = self._calls % self.depth
-        self._calls += 1
         if self.depth == 1:
             self._load(self.static_in[0], inputs)
             self._load(self.static_meta[0], meta_info)
+            self._calls += 1
             self.graphs[0].replay()
             return self.static_out[0]
         main = torch.cuda.current_stream(self.dev)
@@ -85,6 +86,7 @@ class GraphedForward:
             main.wait_event(self._done[i])
         self._load(self.static_in[i], inputs)     # on the CALLER's stream: its tensors are free when we return
         self._load(self.static_meta[i], meta_info)
+        self._calls += 1                          # (a shape error above leaves the pipeline slot where it was)
         ev = torch.cuda.Event()
         ev.record(main)
         st = self._streams[i]
@@ -100,3 +102,7 @@ class GraphedForward:
         for ev in self._done:
             if ev is not None:
                 ev.synchronize()
+
+    def __del__(self):
+        for eng, token in getattr(self, "_tokens", ()):
+            eng.drop_capture(token)

@@ -642,7 +642,7 @@ class HandsLight(EngineSwitches, nn.Module):
         if self.separate_hands and hch:
             hch = 2                # one job per side: the sides have their own weights (model.py:226-228)
         gch, hch = (max(1, min(gch, bz)) if self.use_glb_feat else 0), min(hch, B2)
-        need_cc = self.enc_mode in ("latent", "image")
+        need_cc = (not self.no_crops) and self.enc_mode in ("latent", "image")    # model.py:199-201: no_crops skips every encoding
         center = (torch.cat([f32(inputs["r_center_angle"]), f32(inputs["l_center_angle"])], 0)
                   if (need_cc or self.rot_fix == 2) else None)
         corner = torch.cat([f32(inputs["r_corner_angle"]), f32(inputs["l_corner_angle"])], 0) if need_cc else None
