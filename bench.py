@@ -69,6 +69,9 @@ def parse_args(argv=None):
                     help="replay the forward as a hipGraph (hands_amd.GraphedForward); DEPTH=2 keeps two captured instances "
                          "in flight (handoccnet_light only)")
     ap.add_argument("--layer-report", default="", help="write a per-launch CSV of the MFMA kernels here")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not take the same-run rocprofv3 --pmc passes (roofline.traffic then comes from a stored summary)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the profiled child: two one-stream forwards
     return ap.parse_args(argv)
 
 
@@ -145,14 +148,104 @@ def launch_ranks(args):
         time.sleep(0.05)
     if rc:
         which = first_bad if first_bad is not None else 0
-        logs[which].flush()
-        logs[which].seek(0)
-        tail = logs[which].read()[-4000:]
         why = f"rank {which} exited with code {procs[which].returncode}" if first_bad is not None else "timed out"
-        sys.stderr.write(f"bench.py launcher: {why} (rank logs: {logdir})\n--- rank {which} stderr (tail) ---\n{tail}\n")
+        sys.stderr.write(f"bench.py launcher: {why} (rank logs: {logdir})\n")
+        # the first failing rank in full, then a short tail of every other rank (a hang of rank 3 shows up as rank 0's
+        # watchdog message: the cause is in another log)
+        for r in [which] + [r for r in range(args.gpus) if r != which]:
+            logs[r].flush()
+            logs[r].seek(0)
+            tail = logs[r].read()[-(4000 if r == which else 600):]
+            sys.stderr.write(f"--- rank {r} stderr (tail), exit code {procs[r].returncode} ---\n{tail}\n")
     for log in logs:
         log.close()
     return rc
+
+
+# ------------------------------------------------------------------------------------------------------
+# same-run HBM traffic: two rocprofv3 --pmc child passes, started BEFORE this process touches the GPU
+# ------------------------------------------------------------------------------------------------------
+SAME_RUN_PMC = {}
+
+
+def csrc_sha16():
+    """Hash of the kernel sources the running library was built from (the .so itself carries build paths / timestamps)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "hands_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "hands_amd", "csrc", "*.h"))
+                     + glob.glob(os.path.join(ROOT, "hands_amd", "csrc", "*.cpp")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(fn).encode())
+        h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_sum_conv_dispatches(csv_path, counter):
+    """(sum of `counter` over the conv_igemm* / conv_wino* dispatches, number of such dispatches) of a rocprofv3
+    counter_collection.csv -- the same selection as tools/pmc_summary.py."""
+    import csv
+    tot, disp = 0.0, set()
+    with open(csv_path) as fh:
+        for r in csv.DictReader(fh):
+            if ("conv_igemm" in r["Kernel_Name"] or "conv_wino" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
+                tot += float(r["Counter_Value"])
+                disp.add(r["Dispatch_Id"])
+    return tot, len(disp)
+
+
+def same_run_pmc(args, workload, bz):
+    """HBM bytes of the GEMM / convolution launches measured IN THIS RUN: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
+    (separate passes, no trace domains) over a fresh child `python3 bench.py --pmc-child` that runs two one-stream forwards
+    (the mode `roofline` is defined in).  The children are started and finished before this process makes its first GPU
+    call (a process that has opened the GPU must not be followed by an exec on this pool).  Bytes = 2 x FETCH_SIZE + WRITE_SIZE
+    (KB; MI355X_MICROARCH.md, HBM section: gfx950 reports half of a wide read stream), per launch.  Returns a dict or None."""
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rocprof is None:
+        return {"error": "rocprofv3 not found"}
+    t0 = time.time()
+    tmp = tempfile.mkdtemp(prefix="hands_pmc_", dir="/tmp" if os.path.isdir("/tmp") else None)
+    env = dict(os.environ, TMPDIR=tmp, HANDS_BENCH_PMC_CHILD="1")
+    sums = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-child", "--workload", workload, "--bz", str(bz)]
+            try:
+                p = subprocess.run(cmd, env=env, cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                   timeout=float(os.environ.get("HANDS_PMC_TIMEOUT", "300")))
+            except subprocess.TimeoutExpired:
+                return {"error": f"{counter} pass timed out"}
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return {"error": f"{counter} pass rc {p.returncode}: " + p.stderr.decode(errors="replace")[-200:]}
+            sums[counter] = pmc_sum_conv_dispatches(files[0], counter)
+        (f_kb, nf), (w_kb, nw) = sums["FETCH_SIZE"], sums["WRITE_SIZE"]
+        if nf == 0 or nf != nw:
+            return {"error": f"dispatch counts differ: {nf} vs {nw}"}
+        return {"gb_per_launch": (2.0 * f_kb + w_kb) * 1024 / nf / 1e9, "read_gb_per_launch": 2.0 * f_kb * 1024 / nf / 1e9,
+                "write_gb_per_launch": w_kb * 1024 / nf / 1e9, "dispatches": nf, "bz": bz, "workload": workload,
+                "seconds": round(time.time() - t0, 1),
+                "source": "same-run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE child passes, 2 one-stream forwards each"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_child(args):
+    """The process the counter passes profile: the model of the headline, two forwards in the one-stream mode."""
+    import torch
+    import hands_amd
+    wl = args.workload
+    ctor = {"hamer_light": hands_amd.HAMER, "handoccnet_light": hands_amd.HandOccNet}.get(wl, hands_amd.HandsLight)
+    model = hands_amd.apply_recipe(ctor()).to("cuda").eval()
+    model.overlap_trunks = False
+    inputs, meta = hands_amd.synthetic_inputs(args.bz or default_bz(wl, 1), seed=0, device="cuda")
+    for _ in range(2):
+        dict(model(inputs, meta).items())
+        torch.cuda.synchronize()
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -192,14 +285,18 @@ def pmc_traffic_per_launch(workload, bz):
     """(GB per conv_igemm launch, source file) from the newest committed rocprofv3 --pmc summary TAKEN AT THIS BATCH SIZE,
     or (None, None): a per-launch traffic figure of another batch size must never be divided by this run's algorithmic
     bytes (round 2 printed 8.68x for handoccnet_light that way)."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         for fn in (os.path.join(ROOT, "profiles", f"{rnd}_pmc_{workload}_bz{bz}.json"),
                    os.path.join(ROOT, "profiles", f"{rnd}_pmc_{workload}.json")):
             try:
                 d = json.load(open(fn))
                 if int(d.get("bz", PMC_LEGACY_BZ.get(workload, -1))) != int(bz):
                     continue
-                return round(d["hbm_gb_per_launch"], 4), os.path.relpath(fn, ROOT)
+                # a stored figure describes the binary it was taken with: summaries carry the hash of the kernel sources
+                # (tools/pmc_summary.py); one without it, or of other sources, is reported as stale and NOT used
+                if d.get("csrc_sha16") != csrc_sha16():
+                    return None, "stale (kernel sources changed since): " + os.path.relpath(fn, ROOT)
+                return round(d["hbm_gb_per_launch"], 4), "stored: " + os.path.relpath(fn, ROOT)
             except (OSError, ValueError, KeyError):
                 continue
     return None, None
@@ -208,7 +305,7 @@ def pmc_traffic_per_launch(workload, bz):
 def pmc_shipped_gb_per_step(workload, bz):
     """(GB per forward over the conv launches of the SHIPPED mode, source file) from the newest committed shipped-mode counter
     summary taken at this batch size (tools/profile_round.sh: HANDS_BENCH_SHIPPED_ONLY passes), or (None, None)."""
-    for rnd in ("r04",):
+    for rnd in ("r05", "r04"):
         fn = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{workload}_bz{bz}_shipped.json")
         try:
             d = json.load(open(fn))
@@ -539,7 +636,13 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
     igemm = [d for k, d in per.items() if k.startswith("conv_igemm")]
     ig_ms = sum(d["ms"] for d in igemm) / n_prof
     ig_flop = sum(d["flop"] for d in igemm) / n_prof
-    traffic, traffic_src = pmc_traffic_per_launch(workload, bz)
+    sr = SAME_RUN_PMC.get((workload, bz))
+    if sr and "gb_per_launch" in sr:
+        traffic, traffic_src = round(sr["gb_per_launch"], 4), sr["source"]
+    else:
+        traffic, traffic_src = pmc_traffic_per_launch(workload, bz)
+        if sr and "error" in sr:
+            traffic_src = f"{traffic_src} (same-run pass failed: {sr['error'][:80]})"
     ship_gb, ship_src = pmc_shipped_gb_per_step(workload, bz)
     fam_alg_gb_step = sum(d["bytes"] for d in fam) / n_prof / 1e9
     if math == "bf16x3":
@@ -821,13 +924,13 @@ def measure_lbs(ctx, bz, steps, warmup, with_cpu=True):
 # ------------------------------------------------------------------------------------------------------
 HEADLINE_LIMIT = 4096
 ROOFLINE_KEYS = ("bound", "mode", "kernel", "achieved", "peak", "unit", "frac", "executed_frac", "dominant", "frac_on_own_roof",
-                 "by_bound", "traffic", "traffic_over_algorithmic", "traffic_shipped_over_algorithmic", "kernel_ms_per_step",
+                 "by_bound", "traffic", "traffic_source", "traffic_over_algorithmic", "traffic_shipped_over_algorithmic", "kernel_ms_per_step",
                  "step_ms_same_mode",
                  "launches_per_step", "us_per_launch", "device_ms_per_step", "hbm_gbs")
 CPU_KEYS = ("value", "unit", "cores", "kind", "bz", "sample")
 PARITY_KEYS = ("mpjpe_vs_ref_mm", "max_vertex_err_m", "checked_hands", "worst_vertex_err_m", "worst_seed", "sweep_seeds", "bar_m")
 CONFIG_KEYS = ("workload", "per_gpu_batch", "global_batch", "parallelism", "rccl_ranks", "collective_backend", "launched_by",
-               "timed_mode", "conv3x3_stride1", "steps", "warmup")
+               "timed_mode", "conv3x3_stride1", "steps", "warmup", "allgather_selfcheck_us")
 
 
 def _pick(d, keys):
@@ -871,6 +974,8 @@ def compact_headline(full, also=None, details_path=None):
     if len(json.dumps(line)) >= HEADLINE_LIMIT:          # a pathological string somewhere: keep the contract keys only
         line["config"] = {"workload": str((full.get("config") or {}).get("workload"))[:200]}
         line["roofline"] = _pick(full.get("roofline"), ("bound", "achieved", "peak", "unit", "frac", "traffic"))
+        if line["roofline"] and (full.get("roofline") or {}).get("traffic_source"):
+            line["roofline"]["traffic_source"] = str(full["roofline"]["traffic_source"])[:40]
         line["cpu_baseline"] = _pick(full.get("cpu_baseline"), ("value", "unit", "cores", "kind"))
     return line
 
@@ -902,9 +1007,35 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))       # pure launcher: no GPU call was made in this process
 
+    if args.pmc_child:
+        return pmc_child(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if (world == 1 and args.workload != "mano_lbs" and not args.no_pmc and not args.latency_mode and not args.graph
+            and not os.environ.get("HANDS_BENCH_PMC_CHILD") and not os.environ.get("ROCPROFILER_LIBRARY_CTOR")
+            and "rocprof" not in os.environ.get("LD_PRELOAD", "") and not os.environ.get("HANDS_BENCH_SHIPPED_ONLY")):
+        # before the first GPU call of this process: the counter passes are children with their own GPU context
+        wl0 = args.workload
+        bz0 = args.bz or default_bz(wl0, 1)
+        try:
+            SAME_RUN_PMC[(wl0, bz0)] = same_run_pmc(args, wl0, bz0)
+        except Exception as e:                 # the headline must survive a failure of the counter passes
+            SAME_RUN_PMC[(wl0, bz0)] = {"error": f"{type(e).__name__}: {e}"[:200]}
     pin_to_gpu_numa_node()                 # before the first GPU call of this rank (no re-exec, no numactl)
     ctx = Ctx(args)
     torch = ctx.torch
+    selfcheck = None
+    if ctx.world > 1:
+        # first contact of the ranks over the fabric, on the packed prediction layout, before anything is timed: a dead
+        # peer / corrupted segment ends THIS rank with code 3 / 4 and a message on its stderr (the launcher prints every
+        # rank's tail; under torchrun the agent reports the failing rank)
+        from hands_amd.dist import allgather_selfcheck
+        try:
+            selfcheck = allgather_selfcheck("cpu" if ctx.host_collective else ctx.dev,
+                                            timeout_s=float(os.environ.get("HANDS_SELFCHECK_TIMEOUT", "20")))
+        except RuntimeError as e:
+            sys.stderr.write(str(e) + "\n")
+            sys.stderr.flush()
+            os._exit(4)
     wl = args.workload
     bz = args.bz or default_bz(wl, ctx.world)
     strong = wl in GLOBAL_BATCH and not args.bz
@@ -934,6 +1065,7 @@ def main():
             "config": {"workload": workload_text(wl, bz, ctx.world), "per_gpu_batch": bz, "global_batch": bz * ctx.world,
                        "img_res": 224, "parallelism": f"dp{ctx.world}" + ("+allgather" if ctx.world > 1 else ""),
                        "rccl_ranks": ctx.rccl_ranks, "collective_backend": ctx.backend if ctx.world > 1 else None,
+                       "allgather_selfcheck_us": selfcheck["us"] if selfcheck else None,
                        "launched_by": "bench.py launcher" if os.environ.get("HANDS_BENCH_LAUNCHED") else
                                       ("torchrun" if ctx.world > 1 else "direct"),
                        "timed_mode": ("serial" if args.serial else "multi-stream") + (f"+hipgraph(depth={args.graph})" if args.graph else ""),

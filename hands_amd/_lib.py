@@ -125,7 +125,7 @@ SIGNATURES = {
 EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string", "hands_conv2d_workspace_floats", "hands_pack_conv3x3_winograd_floats", "hands_conv3x3_winograd_executed_macs",
                  "hands_conv2d_streamk_workspace_bytes", "hands_stream_is_capturing")
 
-ABI_VERSION = 3      # HANDS_ABI_VERSION of include/hands_hip.h this wrapper was written against
+ABI_VERSION = 4      # HANDS_ABI_VERSION of include/hands_hip.h this wrapper was written against
 _lib = None
 
 

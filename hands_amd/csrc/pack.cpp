@@ -178,4 +178,37 @@ int hands_pack_conv3x3_winograd_f64(int Cout, int Cin, const double* w_oihw, flo
   return 0;
 }
 
+// Winograd F(4x4, 3x3) weights for hands_conv3x3_winograd4_f32: U = G g G^T (6x6 per (cout, cin)) in fp64, one rounding to
+// fp32, MFMA-A operand order [Cout/32][Cin/8][f = 6 xi + nu][lane 64][4]: lane l of frequency f holds output channel
+// 32 nb + (l & 31), input channels 8 c8 + 4 (l >> 5) + 0..3.
+//   G = [[1/4, 0, 0], [-1/6, -1/6, -1/6], [-1/6, 1/6, -1/6], [1/24, 1/12, 1/6], [1/24, -1/12, 1/6], [0, 0, 1]]
+long long hands_pack_conv3x3_winograd4_floats(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0 || Cout % 32 || Cin % 8) return 0;
+  return 36LL * Cout * Cin;
+}
+
+int hands_pack_conv3x3_winograd4_f64(int Cout, int Cin, const double* w_oihw, float* u_packed) {
+  if (!w_oihw || !u_packed || Cout <= 0 || Cin <= 0 || Cout % 32 || Cin % 8) return HANDS_EINVAL;
+  static const double G[6][3] = {{1.0 / 4, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+  const int nc8 = Cin / 8;
+  for (int o = 0; o < Cout; ++o) {
+    const int nb = o / 32, ol = o % 32;
+    for (int c = 0; c < Cin; ++c) {
+      const double* g = w_oihw + ((long long)o * Cin + c) * 9;
+      double t[6][3];
+      for (int x = 0; x < 6; ++x)
+        for (int j = 0; j < 3; ++j) t[x][j] = G[x][0] * g[0 * 3 + j] + G[x][1] * g[1 * 3 + j] + G[x][2] * g[2 * 3 + j];
+      const int c8 = c / 8, h = (c % 8) / 4, e = c % 4;
+      for (int x = 0; x < 6; ++x)
+        for (int n = 0; n < 6; ++n) {
+          const double u = t[x][0] * G[n][0] + t[x][1] * G[n][1] + t[x][2] * G[n][2];
+          const long long idx = ((((long long)nb * nc8 + c8) * 36 + x * 6 + n) * 64 + (h * 32 + ol)) * 4 + e;
+          u_packed[idx] = (float)u;
+        }
+    }
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -153,3 +153,73 @@ def data_parallel_forward(model, inputs, meta_info, group=None, gather_on_host=F
     if gather_on_host:
         out = {k: v.cpu() for k, v in out.items()}
     return gather_predictions(out, group, global_bz=bz if world > 1 else None)
+
+
+PACKED_WIDTH = 5171      # fp32 columns of one packed sample pair (the 22 prediction tensors of a forward)
+
+
+def allgather_selfcheck(device, rows: int = 32, width: int = PACKED_WIDTH, timeout_s: float = 20.0, group=None,
+                        _corrupt: bool = False) -> dict:
+    """First-contact check of the prediction all-gather on the layout the forward uses (one ``(rows, width)`` fp32 buffer per
+    rank, ``all_gather_into_tensor`` -- RCCL on the GPU box, gloo in the CPU test): every rank fills its buffer with a pattern
+    that encodes (rank, row, column) in exactly representable integers, gathers, and verifies EVERY rank's segment.
+
+    A collective that never returns (a peer died, a link is down) cannot be cancelled from Python, so a watchdog thread ends
+    this process with exit code 3 after ``timeout_s``; a mismatch raises ``RuntimeError`` (bench.py exits with code 4).  No
+    process is re-executed.  Returns ``{"ranks", "us", "rows", "width"}`` -- ``us`` = wall time of the checked collective."""
+    import os
+    import sys
+    import threading
+    import time
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return {"ranks": 1, "us": 0.0, "rows": rows, "width": width}
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = torch.device(device)
+
+    def pattern(r):
+        i = torch.arange(rows, dtype=torch.int64, device=dev).view(-1, 1)
+        j = torch.arange(width, dtype=torch.int64, device=dev).view(1, -1)
+        return ((r * 7919 + i * 131 + j * 17) % 65521).to(torch.float32)       # < 2^24: exact in fp32
+
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(timeout_s):
+            sys.stderr.write(f"hands_amd.dist.allgather_selfcheck: rank {rank} of {world}: the all-gather did not complete "
+                             f"within {timeout_s:.0f} s (a peer is gone or the fabric is down) -- exiting with code 3\n")
+            sys.stderr.flush()
+            os._exit(3)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        mine = pattern(rank)
+        if _corrupt:
+            mine[rows // 2, width // 2] += 1.0
+        full = torch.empty((world * rows, width), dtype=torch.float32, device=dev)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        single = _single_buffer_gather.get((dist.get_backend(group), dev.type), True)
+        if single:
+            try:
+                dist.all_gather_into_tensor(full, mine, group=group)
+            except (NotImplementedError, RuntimeError) as e:
+                msg = str(e).lower()
+                if not isinstance(e, NotImplementedError) and not any(
+                        t in msg for t in ("allgather_base", "all_gather_into_tensor", "allgather_into_tensor")):
+                    raise
+                single = _single_buffer_gather[(dist.get_backend(group), dev.type)] = False
+        if not single:
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine, group=group)
+            full = torch.cat(parts, 0)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        us = (time.perf_counter() - t0) * 1e6
+        bad = [r for r in range(world) if not torch.equal(full[r * rows:(r + 1) * rows], pattern(r))]
+    finally:
+        done.set()
+    if bad:
+        raise RuntimeError(f"hands_amd.dist.allgather_selfcheck: rank {rank} of {world}: the segments of rank(s) {bad} arrived "
+                           f"corrupted ({rows} x {width} fp32 per rank, backend {dist.get_backend(group)})")
+    return {"ranks": world, "us": round(us, 1), "rows": rows, "width": width}

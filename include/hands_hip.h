@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define HANDS_EINVAL 10001
-#define HANDS_ABI_VERSION 3
+#define HANDS_ABI_VERSION 4
 
 typedef void* hands_stream_t;
 
@@ -97,6 +97,18 @@ int hands_conv3x3_winograd_supported(const hands_conv_desc* d);
 long long hands_conv3x3_winograd_executed_macs(const hands_conv_desc* d);
 int hands_conv3x3_winograd_f32(const hands_conv_desc* d, const float* in, const float* u_packed, const float* bias,
                                float* out, hands_stream_t stream);
+
+/* The same layer as Winograd F(4x4, 3x3) (csrc/conv_wino4.hip, round 5): 36 multiplications per 4x4 output pixels and
+ * (cin, cout) pair -- 2.25 per output against 4 for F(2x2, 3x3) and 9 for the direct form.  Same semantics and restrictions as
+ * hands_conv3x3_winograd_f32 (Cin % 8 == 0, Cin >= 16, Cout % 32 == 0, no residual; conv2 / bn2 / relu of a stride-1
+ * Bottleneck, src/nets/backbone/resnet.py:140-142); `u_packed` is the hands_pack_conv3x3_winograd4_f64 form of the BN-folded
+ * weight.  fp32 throughout in a fixed, batch-size-independent order; the larger transform constants of F(4x4) make the
+ * per-layer rounding error ~20x that of F(2x2) (still fp32 noise: DESIGN.md), so a model opts in per layer family
+ * (HandsLight: on, HandOccNet: off).  _executed_macs counts 36 per 4x4 tile and (cin, cout) pair, idle tile lanes included. */
+int hands_conv3x3_winograd4_supported(const hands_conv_desc* d);
+long long hands_conv3x3_winograd4_executed_macs(const hands_conv_desc* d);
+int hands_conv3x3_winograd4_f32(const hands_conv_desc* d, const float* in, const float* u_packed, const float* bias,
+                                float* out, hands_stream_t stream);
 
 /* Deterministic split-K form of the same layer for latency-bound GEMMs (1x1 / linear layers with few
  * rows and a long K: the HMR / decoder / regressor heads).  hands_conv2d_splitk_factor() returns the
@@ -521,6 +533,9 @@ int hands_warp_affine_cubic_norm_f32(const float* src, const float* trans, float
  *   hands_pack_conv3x3_winograd_f64  U = G g G^T (fp64, rounded once) of a (Cout, Cin, 3, 3) weight in MFMA operand
  *                          order for hands_conv3x3_winograd_f32; hands_pack_conv3x3_winograd_floats = 16 * Cout * Cin
  *                          (0 if the shape is not supported: Cout % 32, Cin % 16).
+ *   hands_pack_conv3x3_winograd4_f64  the F(4x4, 3x3) form: U = G g G^T with the 6x3 G of Lavin & Gray, operand order
+ *                          [Cout/32][Cin/8][f = 6 xi + nu][lane 64][4] for hands_conv3x3_winograd4_f32; _floats = 36 * Cout * Cin
+ *                          (0 if unsupported: Cout % 32, Cin % 8).
  * hands_conv2d_workspace_floats: floats of split-K workspace hands_conv2d_nhwc_splitk_n_f32 needs for
  *   S slices (S <= 0: the library's own hands_conv2d_splitk_factor); 0 when no split is taken.
  * --------------------------------------------------------------------------------------------- */
@@ -552,6 +567,8 @@ int hands_pack_mano_f32(const float* v_template, const float* shapedirs, const f
 long long hands_conv2d_workspace_floats(const hands_conv_desc* d, int S);
 long long hands_pack_conv3x3_winograd_floats(int Cout, int Cin);
 int hands_pack_conv3x3_winograd_f64(int Cout, int Cin, const double* w_oihw, float* u_packed);
+long long hands_pack_conv3x3_winograd4_floats(int Cout, int Cin);
+int hands_pack_conv3x3_winograd4_f64(int Cout, int Cin, const double* w_oihw, float* u_packed);
 
 #ifdef __cplusplus
 }
