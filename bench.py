@@ -999,6 +999,8 @@ def conv3x3_route(model):
         return None
     if not model.engine.winograd:
         return "direct"
+    if getattr(model.engine, "winograd4", False) and getattr(model, "winograd4_stages", ()):
+        return "winograd_f4x4:stages" + "".join(str(i) for i in model.winograd4_stages)     # (F(2x2) where F(4x4) is not packed)
     return "winograd_f2x2" + (f":{model.winograd_scope}" if hasattr(model, "winograd_scope") else "")
 
 

@@ -59,6 +59,8 @@ SIGNATURES = {
     "hands_conv2d_nhwc_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P],
     "hands_conv3x3_winograd_supported": [C.POINTER(ConvDesc)],
     "hands_conv3x3_winograd_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
+    "hands_conv3x3_winograd4_supported": [C.POINTER(ConvDesc)],
+    "hands_conv3x3_winograd4_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
     "hands_conv2d_splitk_factor": [C.POINTER(ConvDesc)],
     "hands_conv2d_nhwc_splitk_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_longlong, _P],
     "hands_conv2d_streamk_grid": [C.POINTER(ConvDesc)],
@@ -121,8 +123,10 @@ SIGNATURES = {
     "hands_pack_conv1x1_dual_f64": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
     "hands_pack_mano_f32": [_P] * 10,
     "hands_pack_conv3x3_winograd_f64": [_I, _I, _P, _P],
+    "hands_pack_conv3x3_winograd4_f64": [_I, _I, _P, _P],
 }
 EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string", "hands_conv2d_workspace_floats", "hands_pack_conv3x3_winograd_floats", "hands_conv3x3_winograd_executed_macs",
+                 "hands_pack_conv3x3_winograd4_floats", "hands_conv3x3_winograd4_executed_macs",
                  "hands_conv2d_streamk_workspace_bytes", "hands_stream_is_capturing")
 
 ABI_VERSION = 4      # HANDS_ABI_VERSION of include/hands_hip.h this wrapper was written against
@@ -156,6 +160,10 @@ def lib():
     h.hands_pack_conv3x3_winograd_floats.argtypes = [C.c_int, C.c_int]
     h.hands_conv3x3_winograd_executed_macs.restype = C.c_longlong
     h.hands_conv3x3_winograd_executed_macs.argtypes = [C.POINTER(ConvDesc)]
+    h.hands_pack_conv3x3_winograd4_floats.restype = C.c_longlong
+    h.hands_pack_conv3x3_winograd4_floats.argtypes = [C.c_int, C.c_int]
+    h.hands_conv3x3_winograd4_executed_macs.restype = C.c_longlong
+    h.hands_conv3x3_winograd4_executed_macs.argtypes = [C.POINTER(ConvDesc)]
     h.hands_abi_version.restype = C.c_int
     h.hands_stream_is_capturing.restype = C.c_int
     h.hands_stream_is_capturing.argtypes = [C.c_void_p]

@@ -38,6 +38,9 @@ class ConvEngine:
         self.winograd = True          # 3x3 / stride 1 / pad 1 layers as Winograd F(2x2,3x3) on the fp32 matrix cores
                                       # (hands_conv3x3_winograd_f32: 2.25x fewer multiplications; fp32 throughout, results
                                       # differ from the direct kernel by fp32 rounding).  False = the direct implicit GEMM
+        self.winograd4 = False        # the same layers as Winograd F(4x4,3x3) (hands_conv3x3_winograd4_f32: 2.25 multiplications per
+                                      # output instead of 4) where the layer was packed for it (PackedConv.wino4) and the library
+                                      # takes the shape; HandsLight turns it on, HandOccNet keeps F(2x2) (DESIGN.md "Conditioning note")
         self.fuse_mano = True         # MANOHead.forward of both hands as one launch (hands_mano_heads_f32)
         self.fuse_pre = True          # handoccnet_light's pre-activation units: BatchNorm -> LeakyReLU folded into the operand
                                       # staging of the unit's first (pointwise) convolution (hands_conv2d_nhwc_pre_f32)
@@ -48,6 +51,8 @@ class ConvEngine:
                                       # A fixed function of the layer -- batch-size independent.  HandOccNet sets it (DESIGN.md
                                       # "Conditioning note"); 0 elsewhere
         self.chain_min_k = 0          # launches with Kpad below max(chain_min_k, 2 * chain_limit) keep their single chain
+        self.chain_max_pix = 0        # > 0: only launches on maps of at most this many output pixels per image are blocked (the
+                                      # workspace round trip is per output element: large maps pay most for the same chain)
         self.hook = None              # callable(phase, pc, npix, stream_handle, has_res, kernel): bench.py brackets
                                       # every MFMA launch (conv_igemm and the fused stem) with events; `kernel` is the
                                       # kernel the launch really runs (conv_igemm_f32_kernel / conv_igemm_sk_f32_kernel =
@@ -62,8 +67,8 @@ class ConvEngine:
 
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
-        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "winograd", "fuse_mano", "fuse_pre", "stream_k", "math", "chain_limit",
-                  "chain_min_k"):
+        for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "winograd", "winograd4", "fuse_mano", "fuse_pre", "stream_k", "math", "chain_limit",
+                  "chain_min_k", "chain_max_pix"):
             setattr(e, k, getattr(self, k))
         return e
 
@@ -137,6 +142,17 @@ class ConvEngine:
             tiles = -(-(B * Ho * Wo) // bm) * -(-pc.Cout // bn)
             S = max(S, min(256 // tiles, pc.Kpad // 128, 32)) if tiles <= 128 else S
         rp = ptr(res, res_off) if res is not None else None
+        if (self.winograd and self.winograd4 and pc.wino4 is not None and res is None and pre is None and S <= 1
+                and self.math == "fp32" and (ptr(x, x_off) | ptr(out, out_off)) % 16 == 0
+                and L.hands_conv3x3_winograd4_supported(C.byref(d))):
+            if hook is not None:
+                self.last_wino_macs = L.hands_conv3x3_winograd4_executed_macs(C.byref(d))
+                hook("begin", pc, B * Ho * Wo, stream, False, "conv_wino4_f32_kernel")
+            check(L.hands_conv3x3_winograd4_f32(C.byref(d), ptr(x, x_off), ptr(pc.wino4), ptr(pc.bias), ptr(out, out_off), stream),
+                  "hands_conv3x3_winograd4_f32")
+            if hook is not None:
+                hook("end", pc, B * Ho * Wo, stream, False, "conv_wino4_f32_kernel")
+            return Ho, Wo
         if (self.winograd and pc.wino is not None and res is None and pre is None and S <= 1 and self.math == "fp32"
                 and (ptr(x, x_off) | ptr(out, out_off)) % 16 == 0        # its accesses are 16 bytes wide
                 and L.hands_conv3x3_winograd_supported(C.byref(d))):
@@ -149,7 +165,8 @@ class ConvEngine:
                 hook("end", pc, B * Ho * Wo, stream, False, "conv_wino_f32_kernel")
             return Ho, Wo
         if (self.chain_limit and self.use_splitk and self.math == "fp32"
-                and pc.Kpad >= max(2 * self.chain_limit, self.chain_min_k)):
+                and pc.Kpad >= max(2 * self.chain_limit, self.chain_min_k)
+                and (not self.chain_max_pix or Ho * Wo <= self.chain_max_pix)):
             # blocked summation (not the Winograd launches above: their chains are Cin long)
             S = max(S, min(pc.Kpad // self.chain_limit, 32))
         if pre is not None:

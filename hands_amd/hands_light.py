@@ -268,6 +268,11 @@ class HandsLight(EngineSwitches, nn.Module):
                  mano_assets=None):
         super().__init__()
         self.engine = ConvEngine()
+        # Winograd F(4x4,3x3) (csrc/conv_wino4.hip, 2.25 multiplications per output) for the stride-1 3x3 convolutions of these
+        # ResNet stages; the others keep F(2x2,3x3).  A packing-time choice (the F(4x4) weights are 36 Cout Cin floats per layer):
+        # call invalidate_packed() after changing it.  engine.winograd4 = False falls back to F(2x2) without repacking.
+        self.winograd4_stages = (4,)
+        self.engine.winograd4 = True
         self.trunk_chunks = (1, 2)    # (global, hand) trunk jobs, one HIP stream each
         self.async_tail = True        # tail of the forward on its own stream, joined at first use of the result
         self._calls = 0
@@ -399,7 +404,8 @@ class HandsLight(EngineSwitches, nn.Module):
             for blk in getattr(net, f"layer{li}"):
                 e = {}
                 w, b = fold_bn(cpu(blk.conv1.weight), *bnp(blk.bn1)); e["c1"] = pack_conv(w, b, 1, 0, dev)
-                w, b = fold_bn(cpu(blk.conv2.weight), *bnp(blk.bn2)); e["c2"] = pack_conv(w, b, blk.stride, 1, dev)
+                w, b = fold_bn(cpu(blk.conv2.weight), *bnp(blk.bn2))
+                e["c2"] = pack_conv(w, b, blk.stride, 1, dev, winograd4=li in self.winograd4_stages)
                 w, b = fold_bn(cpu(blk.conv3.weight), *bnp(blk.bn3)); e["c3"] = pack_conv(w, b, 1, 0, dev)
                 if blk.downsample is not None:
                     w, b = fold_bn(cpu(blk.downsample[0].weight), *bnp(blk.downsample[1]))

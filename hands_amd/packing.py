@@ -38,6 +38,7 @@ class PackedConv:
     Kpad: int
     macs_per_pixel: int = 0   # ALGORITHMIC multiply-accumulates per output pixel (true, unpadded dims)
     wino: torch.Tensor = None  # 3x3 / stride 1 / pad 1 layers: Winograd F(2x2,3x3) weights (hands_pack_conv3x3_winograd_f64)
+    wino4: torch.Tensor = None  # the same layers: Winograd F(4x4,3x3) weights (hands_pack_conv3x3_winograd4_f64), when asked for
 
 
 def _f64(t):
@@ -70,9 +71,10 @@ def fold_bn(w, bn_w, bn_b, bn_mean, bn_var, eps=BN_EPS):
     return torch.from_numpy(wf), torch.from_numpy(bf)
 
 
-def pack_conv(w, bias, stride, pad, device, cin_pad_to=None, winograd=True) -> PackedConv:
+def pack_conv(w, bias, stride, pad, device, cin_pad_to=None, winograd=True, winograd4=False) -> PackedConv:
     """w: (Cout, Cin, KH, KW) (any float dtype, CPU); bias: (Cout,) or None.  hands_pack_conv_f64.
-    3x3 / stride 1 / pad 1 layers additionally get the Winograd form of the same folded weight (``pc.wino``)."""
+    3x3 / stride 1 / pad 1 layers additionally get the Winograd form of the same folded weight (``pc.wino``: F(2x2,3x3);
+    ``winograd4=True``: also ``pc.wino4``, the F(4x4,3x3) form, 36 Cout Cin floats)."""
     L = _lib.lib()
     Cout, Cin, KH, KW = w.shape
     d = PackedDims()
@@ -90,6 +92,11 @@ def pack_conv(w, bias, stride, pad, device, cin_pad_to=None, winograd=True) -> P
             up = np.empty(n, np.float32)
             check(L.hands_pack_conv3x3_winograd_f64(Cout, Cin, _p(wn), _p(up)), "hands_pack_conv3x3_winograd_f64")
             pc.wino = torch.from_numpy(up).to(device)
+        n4 = L.hands_pack_conv3x3_winograd4_floats(Cout, Cin) if winograd4 else 0
+        if n4 > 0:
+            up = np.empty(n4, np.float32)
+            check(L.hands_pack_conv3x3_winograd4_f64(Cout, Cin, _p(wn), _p(up)), "hands_pack_conv3x3_winograd4_f64")
+            pc.wino4 = torch.from_numpy(up).to(device)
     return pc
 
 

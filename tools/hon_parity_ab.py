@@ -9,7 +9,7 @@ processes (8 threads each) created before the parent touches the GPU.
 
 usage: python tools/hon_parity_ab.py [--seeds N] [--first S] [--arms a,b,...] [--workers W] [--out gpurun_out/hon_ab.json]
        [--speed]   (hands/s of every arm at bz = 32 and 256, shipped pipelined mode)
-arm syntax: <scope>[+c<chain_limit>[k<chain_min_k>]], scope in direct | trunk | backbone | backbone+fit | all
+arm syntax: <scope>[+c<chain_limit>[k<chain_min_k>][p<chain_max_pix>]], scope in direct | trunk | backbone | backbone+fit | all
 """
 import argparse
 import json
@@ -61,11 +61,12 @@ def wilson(k, n, z=1.96):
 
 def parse_arm(name):
     scope, _, rest = name.partition("+c")
-    limit = min_k = 0
+    limit = min_k = max_pix = 0
     if rest:
+        rest, _, mp = rest.partition("p")
         lim, _, mk = rest.partition("k")
-        limit, min_k = int(lim), int(mk or 0)
-    return scope, limit, min_k
+        limit, min_k, max_pix = int(lim), int(mk or 0), int(mp or 0)
+    return scope, limit, min_k, max_pix
 
 
 def main():
@@ -104,11 +105,11 @@ def main():
     from hands_amd.weights import synthetic_inputs
     models = {}
     for name in arms:
-        scope, limit, min_k = parse_arm(name)
+        scope, limit, min_k, max_pix = parse_arm(name)
         m = hands_amd.apply_recipe(hands_amd.HandOccNet()).to("cuda").eval()
         m.engine.winograd = scope != "direct"
         m.winograd_scope = scope if scope != "direct" else "backbone"
-        m.engine.chain_limit, m.engine.chain_min_k = limit, min_k
+        m.engine.chain_limit, m.engine.chain_min_k, m.engine.chain_max_pix = limit, min_k, max_pix
         m.invalidate_packed()
         m.async_forward = False
         models[name] = m
