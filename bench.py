@@ -494,8 +494,13 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         model.engine.fuse_pre = os.environ["HANDS_FUSE_PRE"] == "1"
     if winograd is not None:                       # the model's own default otherwise
         model.engine.winograd = bool(winograd)
-    if winograd_scope is not None and hasattr(model, "winograd_scope"):    # HandOccNet: default "backbone"
+    if winograd_scope is not None and hasattr(model, "winograd_scope"):    # HandOccNet: default "all" + chains <= 256 floats
         model.winograd_scope = winograd_scope
+        if winograd_scope == "backbone":           # the comparison line: rounds 3-4's default, single fp32 chains
+            model.engine.chain_limit = 0
+        model.invalidate_packed()
+    if os.environ.get("HANDS_WINO4_STAGES") is not None and hasattr(model, "winograd4_stages"):    # developer A/B switch: "", "4", "1234"
+        model.winograd4_stages = tuple(int(c) for c in os.environ["HANDS_WINO4_STAGES"])
         model.invalidate_packed()
     if os.environ.get("HANDS_WINOGRAD"):           # developer A/B switch
         model.engine.winograd = os.environ["HANDS_WINOGRAD"] == "1"
@@ -1001,7 +1006,8 @@ def conv3x3_route(model):
         return "direct"
     if getattr(model.engine, "winograd4", False) and getattr(model, "winograd4_stages", ()):
         return "winograd_f4x4:stages" + "".join(str(i) for i in model.winograd4_stages)     # (F(2x2) where F(4x4) is not packed)
-    return "winograd_f2x2" + (f":{model.winograd_scope}" if hasattr(model, "winograd_scope") else "")
+    return ("winograd_f2x2" + (f":{model.winograd_scope}" if hasattr(model, "winograd_scope") else "")
+            + (f"+chains<={model.engine.chain_limit}" if getattr(model.engine, "chain_limit", 0) else ""))
 
 
 def main():
@@ -1089,19 +1095,19 @@ def main():
             sys.stderr.flush()
 
         # name, bz, steps, warmup, parity bz.  *_bf16x3: separately reported arithmetic mode, never the headline value;
-        # *_winograd_all: HandOccNet's opt-in scope
+        # *_backbone_unblocked: HandOccNet's default of rounds 3-4 (Winograd in the backbone only, single fp32 chains), for comparison
         for name, abz, asteps, awarm, pbz in (("hands_light_bf16x3", 256, 10, 3, 8), ("hamer_light", 64, 4, 1, 1),
                                               ("hamer_light_bf16x3", 64, 4, 1, 1), ("handoccnet_light", 32, 10, 3, 2),
                                               ("handoccnet_light_graph4", 32, 12, 4, 2),
-                                              ("handoccnet_light_winograd_all", 32, 10, 3, 2)):
+                                              ("handoccnet_light_backbone_unblocked", 32, 10, 3, 2)):
             key = name
             try:
                 math, wino, wscope, graph = "fp32", None, None, 0
                 mg = re.search(r"_graph(\d+)$", name)   # hands_amd.GraphedForward(depth=N): N captured forwards in flight
                 if mg:                                   # (depth 2 / 3 / 4 / 6 measured 3617 / 3670 / 3703 / 3752 hands/s, eager 3657)
                     name, graph = name[: mg.start()], int(mg.group(1))
-                if name.endswith("_winograd_all"):
-                    name, wino, wscope = name[: -len("_winograd_all")], True, "all"
+                if name.endswith("_backbone_unblocked"):
+                    name, wino, wscope = name[: -len("_backbone_unblocked")], True, "backbone"
                 if name.endswith("_bf16x3"):
                     name, math = name[: -len("_bf16x3")], "bf16x3"
                 r, m, sd = measure_model(ctx, name, abz, asteps, awarm, args, parity_bz=pbz, math=math, winograd=wino,

@@ -88,16 +88,20 @@ class HandOccNet(EngineSwitches, nn.Module):
         self._packed = None
         self._packed_dev = None
         self.engine = ConvEngine()
-        # Winograd F(2x2,3x3) (engine.winograd) runs in the BACKBONE only by default (ResNet-50 trunk + FPN smoothing: +8.6 % at 32
-        # samples per GPU); the FIT / SET convolutions and the regressor's units stay on the direct kernel.  Winograd's per-layer
-        # error against fp64 is smaller than the direct kernel's, but this network amplifies ANY fp32 re-association (DESIGN.md
-        # "Conditioning note"): over 16 input seeds the max vertex error against the reference's own fp32 output is 3.7-8.0e-7 m
-        # with the direct kernel everywhere, 4.1-8.5e-7 m with this scope and 3.1-9.0e-7 m with Winograd in every 3x3 / stride-1
-        # layer (tools/hon_parity_sweep.py; the reference itself is 2.0-6.0e-7 m from an fp64 evaluation) -- and with "all" one of
-        # the two golden seeds lands at 1.07e-6 m (bar 1e-6 m; this scope 7.8e-7, direct 6.9e-7).  winograd_scope = "all" is the
-        # opt-in (+14 %), engine.winograd = False the direct kernel everywhere; call invalidate_packed() after changing the scope.
+        # Numerics of this network (DESIGN.md "Conditioning note"; round 5: tools/hon_parity_ab.py over 1000 random inputs, the fp32
+        # reference itself sits a median 2.9e-7 m / at most 6.3e-7 m from an fp64 evaluation): it amplifies ANY fp32 re-association,
+        # and what the HIP path adds on top is the length of its fp32 accumulation chains -- one k-ordered FMA chain per output in the
+        # direct kernel against ATen's blocked sums.  Two settings shorten them:
+        #   * winograd_scope = "all": every 3x3 / stride-1 layer as Winograd F(2x2,3x3), whose chains are Cin long instead of 9 Cin
+        #     (and +2-6 % throughput): 0.6 % of inputs above 1e-6 m against 1.1 % with the backbone-only scope of rounds 3-4;
+        #   * engine.chain_limit = 256 (chain_min_k 512): every direct launch with K >= 512 is cut into K / 256 slices by the
+        #     deterministic split-K form, partial sums added in slice order -- no chain longer than 256 floats: 0.3 % [0.10, 0.88]
+        #     above 1e-6 m, maximum 1.07e-6 over 1000 inputs, median HIP-vs-fp64 error 1.49x the reference's own, -4.7 % throughput.
+        # (chain_limit = 128 on every launch: 0 of 1000, median ratio 1.18, -18 %: the opt-in for a caller who wants the margin.)
+        # Call invalidate_packed() after changing the scope.
         self.engine.winograd = True
-        self.winograd_scope = "backbone"   # "all" | "backbone+fit" | "backbone" (trunk + FPN smoothing) | "trunk"
+        self.winograd_scope = "all"        # "all" | "backbone+fit" | "backbone" (trunk + FPN smoothing) | "trunk"
+        self.engine.chain_limit, self.engine.chain_min_k = 256, 512
         self.small_map_splitk = True   # call-site constant split-K on maps of <= 8x8 pixels (see _conv_fns)
         self.chunks = 2   # the 2*bz crops run as this many jobs on separate HIP streams (1 = single stream)
         self.async_forward = True   # two forwards in flight: call i runs on pipeline stream i & 1 and is joined at the first

@@ -269,9 +269,13 @@ class HandsLight(EngineSwitches, nn.Module):
         super().__init__()
         self.engine = ConvEngine()
         # Winograd F(4x4,3x3) (csrc/conv_wino4.hip, 2.25 multiplications per output) for the stride-1 3x3 convolutions of these
-        # ResNet stages; the others keep F(2x2,3x3).  A packing-time choice (the F(4x4) weights are 36 Cout Cin floats per layer):
-        # call invalidate_packed() after changing it.  engine.winograd4 = False falls back to F(2x2) without repacking.
-        self.winograd4_stages = (4,)
+        # ResNet stages; the others keep F(2x2,3x3).  Round 5, one box, alternating: alone on the chip a launch takes the time of its
+        # F(2x2) twin (layers 1-3) or 9 % less (layer 4), but it spends ~45 % fewer matrix-pipe cycles, and in the shipped multi-stream
+        # mode that is +1.6 % on the forward with all four stages (+0.4 % with stage 4 only); end-to-end error over 200 random inputs
+        # unchanged (median 2.4e-7 m, max 4.4e-7 against 2.5e-7 / 4.9e-7 with F(2x2): tools/hl_parity_sweep.py).  A packing-time
+        # choice (36 Cout Cin floats per layer, 130 MB per trunk): call invalidate_packed() after changing it; engine.winograd4 = False
+        # falls back to F(2x2) without repacking.
+        self.winograd4_stages = (1, 2, 3, 4)
         self.engine.winograd4 = True
         self.trunk_chunks = (1, 2)    # (global, hand) trunk jobs, one HIP stream each
         self.async_tail = True        # tail of the forward on its own stream, joined at first use of the result

@@ -735,11 +735,11 @@ def test_forward_with_the_direct_3x3_kernel_vs_golden(golden_dir, gpu_model):
     gpu_model.overlap_trunks = False
     try:
         w = {k: v.clone() for k, v in gpu_model(inputs, meta).items()}
-        n_wino = seen.count("conv_wino_f32_kernel")
+        n_wino = seen.count("conv_wino_f32_kernel") + seen.count("conv_wino4_f32_kernel")     # F(2x2) and F(4x4) (winograd4_stages)
         gpu_model.engine.winograd = False
         seen.clear()
         o = {k: v.clone() for k, v in gpu_model(inputs, meta).items()}
-        assert n_wino > 0 and n_wino % (2 * 13) == 0 and "conv_wino_f32_kernel" not in seen     # 13 stride-1 3x3 layers per trunk job
+        assert n_wino > 0 and n_wino % (2 * 13) == 0 and not any(k.startswith("conv_wino") for k in seen)   # 13 stride-1 3x3 layers per trunk job
     finally:
         gpu_model.engine.winograd = True
         gpu_model.conv_hook = None
