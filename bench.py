@@ -310,7 +310,9 @@ def pmc_shipped_gb_per_step(workload, bz):
         try:
             d = json.load(open(fn))
             if int(d.get("bz", -1)) == int(bz) and d.get("gb_per_forward"):
-                return round(d["gb_per_forward"], 3), os.path.relpath(fn, ROOT)
+                if d.get("csrc_sha16") != csrc_sha16():        # taken with other kernel sources: not this binary's figure
+                    return None, "stale (kernel sources changed since): " + os.path.relpath(fn, ROOT)
+                return round(d["gb_per_forward"], 3), "stored: " + os.path.relpath(fn, ROOT)
         except (OSError, ValueError, KeyError):
             continue
     return None, None
