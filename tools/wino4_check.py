@@ -57,6 +57,8 @@ for case in (CASES if "--time-only" not in sys.argv else []):
         torch.cuda.synchronize()
         got = got.cpu().double()
         errs[kind] = float("nan") if not torch.isfinite(got).all() else (got - ref).abs().max().item()
+    import zlib
+    crc = zlib.crc32(run("w4", xd, pc, act).cpu().numpy().tobytes())
     again = run("w4", xd, pc, act)
     first2 = run("w4", xd[:2].contiguous(), pc, act) if B > 2 else None
     torch.cuda.synchronize()
@@ -67,7 +69,7 @@ for case in (CASES if "--time-only" not in sys.argv else []):
     bad += not ok
     print(f"{'ok ' if ok else 'BAD'} {case}: scale {scale:.2f}  err/scale  F(4x4) {errs['w4'] / scale:.2e}"
           + (f"  F(2x2) {errs['w2'] / scale:.2e}" if "w2" in errs else "") + (f"  direct {errs['direct'] / scale:.2e}" if "direct" in errs else "") +
-          f"  deterministic {det}  batch-invariant {inv}", flush=True)
+          f"  deterministic {det}  batch-invariant {inv}  crc {crc:08x}", flush=True)
 print("failures:", bad)
 
 if "--no-time" not in sys.argv:
