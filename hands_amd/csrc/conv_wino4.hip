@@ -126,8 +126,7 @@ constexpr int W4_PATCH_MAX = 36 * 1024;
 // rows as it arrives (fixed order):  y0 = z0 + z1 + z2 + z3 + z4;  y1 = z1 - z2 + 2 z3 - 2 z4;  y2 = z1 + z2 + 4 z3 + 4 z4;
 // y3 = z1 - z2 + 8 z3 - 8 z4 + z5;  then bias, activation, 16-byte NHWC stores.
 template <int D, bool LINEAR, int VSH>
-__device__ __forceinline__ void w4_output_pass(const Wino4Args& a, const char* lds, int wave, int lane, int nb, int R0, int s0, int tx0,
-                                               int chan_off = 0) {
+__device__ __forceinline__ void w4_output_pass(const Wino4Args& a, const char* lds, int wave, int lane, int nb, int R0, int s0, int tx0) {
   constexpr int VM = (1 << VSH) - 1;
   const int rd = wave >> 2, oj = wave & 3;
   const int otl = lane >> 1, ocq = lane & 1;
@@ -136,7 +135,7 @@ __device__ __forceinline__ void w4_output_pass(const Wino4Args& a, const char* l
   const int oV = R0 + oRl, oR = oV >> VSH, otx = tx0 + (oV & VM) * D + ocol;
   const int ob = w4_fastdiv(oR, a.nh_mul, a.nh_sh), oty = oR - ob * a.nh;
   if (!(oR < a.rows && otx < a.nw && 4 * otx + oj < a.W)) return;
-  const int n_ch = nb * 32 + chan_off + rd * 8 + ocq * 4;
+  const int n_ch = nb * 32 + rd * 8 + ocq * 4;
   float* const o = a.out + (((size_t)ob * a.H + 4 * oty) * a.W + 4 * otx + oj) * (size_t)a.out_ps + n_ch;
   const char* sE = lds + rd * W4_VBUF + otl * 32 + ocq * 16;
   const float kq = oj == 0 ? 1.f : (oj == 1 ? 2.f : (oj == 2 ? 4.f : 8.f));
@@ -471,254 +470,6 @@ __global__ void __launch_bounds__(1024, 1) conv_wino4_f32_kernel(Wino4Args a) {
   W4_STAMP(1, 61);
 }
 
-
-// ---- persistent form (round 5): one workgroup per CU walks the (channel block, tile block) items i = slot, slot + G, ... ----------
-// What it buys over one workgroup per item: no dispatch gap between items (~2 us of a 26 us item on layer 1), and the first two
-// stages of the NEXT item's patch are fetched during this item's output transform -- the exchange goes through the two V buffers
-// only (two rounds of 16 channels, waves 0-7 finish them), so the patch buffers are free for the producers' DMA.  The arithmetic
-// of an item is the one-item kernel's, instruction for instruction: same bits.
-template <int D, bool LINEAR, int VSH>
-__global__ void __launch_bounds__(1024, 1) conv_wino4p_f32_kernel(Wino4Args a) {
-  using G = W4Geom<D, LINEAR>;
-  __shared__ __attribute__((aligned(1024))) char lds[4 * W4_VBUF];
-  char* const sV = lds;
-  char* const sP = lds + 2 * W4_VBUF;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave >= 12;
-  const int l31 = lane & 31, half = lane >> 5;
-  constexpr int VM = (1 << VSH) - 1;
-  const int nitems = a.nblk_m * a.nblk_n;
-  const int Gn = gridDim.x;
-  const int nsteps = a.Cin >> 3;
-  int item = w4_xcd_remap(blockIdx.x, Gn);                      // items of one round form one contiguous range per XCD
-
-#define W4_DECODE(ITEM)                                                                              \
-  const int nb = (ITEM) / a.nblk_m, mb = (ITEM) - nb * a.nblk_m;                                    \
-  int R0, s0, tx0;                                                                                  \
-  if constexpr (LINEAR) {                                                                           \
-    const int t0 = mb * 32;                                                                         \
-    R0 = t0 / D; s0 = t0 - R0 * D; tx0 = 0;                                                         \
-  } else {                                                                                          \
-    const int rb = mb / a.nseg, seg = mb - rb * a.nseg;                                             \
-    R0 = rb * G::NR; s0 = 0; tx0 = seg * D;                                                         \
-  }                                                                                                 \
-  const int R0r = R0 >> VSH;                                                                        \
-  const int b_first = w4_fastdiv(R0r, a.nh_mul, a.nh_sh);                                           \
-  const int ty_first = R0r - b_first * a.nh
-
-  if (producer) {
-    const int pw = wave - 12;
-    __builtin_amdgcn_s_setprio(2);
-    int f_off[G::NJ], tb[6];
-    __amdgpu_buffer_rsrc_t x_rsrc;
-    // per item: DMA source offsets of this lane's slot of pieces pw, pw + 4, ... and the patch read addresses of its (tile, channel)
-#define W4_PSETUP(ITEM)                                                                              \
-  do {                                                                                              \
-    W4_DECODE(ITEM);                                                                                \
-    (void)nb;                                                                                       \
-    x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in) + (size_t)b_first * a.H * a.W * a.in_ps, 0,  \
-                                               (int)0x80000000u, 0x00020000);                       \
-    _Pragma("unroll") for (int j = 0; j < G::NJ; ++j) {                                             \
-      const int i = j * 4 + pw;                                                                     \
-      const int S = i * 64 + lane;                                                                  \
-      const int r = S / (G::PWP * 2), within = S - r * (G::PWP * 2);                                \
-      const int Rl = r / 6, ar = r - Rl * 6;                                                        \
-      const int xg = within >> 3, sl = within & 7;                                                  \
-      const int swz = (D * Rl + xg) & 3;                                                            \
-      const int sl2 = sl ^ (swz << 1);                                                              \
-      const int x = 4 * xg + (sl2 >> 1), q = sl2 & 1;                                               \
-      const int V = R0 + Rl, Rr = V >> VSH, pv = V & VM;                                            \
-      const int t = ty_first + (Rr - R0r);                                                          \
-      const int db = w4_fastdiv(t, a.nh_mul, a.nh_sh), ty = t - db * a.nh;                          \
-      const int hy = 4 * ty - 1 + ar, wx = 4 * (tx0 + pv * D) - 1 + x;                              \
-      const bool ok = i < G::PIECES && x < G::PW && Rr < a.rows && (unsigned)hy < (unsigned)a.H && (unsigned)wx < (unsigned)a.W; \
-      f_off[j] = ok ? (((db * a.H + hy) * a.W + wx) * a.in_ps + q * 4) * 4 : (int)0x80000000u;      \
-    }                                                                                               \
-    const int tl = pw * 8 + (lane >> 3), c = lane & 7;                                              \
-    const int qq = s0 + tl;                                                                         \
-    const int Rl = LINEAR ? qq / D : tl / D, col = LINEAR ? qq - Rl * D : tl - Rl * D;              \
-    const int swz0 = (D * Rl + col) & 3, swz1 = (swz0 + 1) & 3;                                     \
-    const int q = c >> 2, w = c & 3;                                                                \
-    _Pragma("unroll") for (int b = 0; b < 6; ++b) {                                                 \
-      const int grp8 = b < 4 ? col : col + 1;                                                       \
-      const int sl = (2 * (b & 3) + q) ^ ((b < 4 ? swz0 : swz1) << 1);                              \
-      tb[b] = Rl * 6 * G::ROW_BYTES + (grp8 * 8 + sl) * 16 + w * 4;                                 \
-    }                                                                                               \
-  } while (0)
-#define W4_PFILL(PB, G_)                                                                             \
-  do {                                                                                              \
-    _Pragma("unroll") for (int j = 0; j < G::NJ; ++j) {                                             \
-      if (j * 4 + pw < G::PIECES) w4_dma16(x_rsrc, sP + (PB) * W4_VBUF + (j * 4 + pw) * 1024, f_off[j], (G_) * 32); \
-    }                                                                                               \
-  } while (0)
-#define W4_TRANSFORM(PB, VB, NEXT_FILL)                                                              \
-  do {                                                                                              \
-    const char* pp = sP + (PB) * W4_VBUF;                                                           \
-    float xx[6][6];                                                                                 \
-    _Pragma("unroll") for (int b = 0; b < 6; ++b)                                                   \
-      _Pragma("unroll") for (int ar = 0; ar < 6; ++ar)                                              \
-        xx[ar][b] = *reinterpret_cast<const float*>(pp + tb[b] + ar * G::ROW_BYTES);                \
-    __builtin_amdgcn_sched_barrier(0);                                                              \
-    NEXT_FILL;                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                              \
-    float tt[6][6];                                                                                 \
-    _Pragma("unroll") for (int b = 0; b < 6; ++b) {                                                 \
-      float x[6], v[6];                                                                             \
-      _Pragma("unroll") for (int ar = 0; ar < 6; ++ar) x[ar] = xx[ar][b];                           \
-      w4_bt6(x, v);                                                                                 \
-      _Pragma("unroll") for (int k = 0; k < 6; ++k) tt[k][b] = v[k];                                \
-    }                                                                                               \
-    char* vp = sV + (VB) * W4_VBUF + vw_off;                                                        \
-    _Pragma("unroll") for (int k = 0; k < 6; ++k) {                                                 \
-      float v[6];                                                                                   \
-      w4_bt6(tt[k], v);                                                                             \
-      _Pragma("unroll") for (int n = 0; n < 6; ++n) *reinterpret_cast<float*>(vp + (k * 6 + n) * 1024) = v[n]; \
-    }                                                                                               \
-  } while (0)
-    const int vw_off = pw * 256 + lane * 4;
-    W4_PSETUP(item);
-    W4_PFILL(0, 0);
-    if (nsteps > 1) W4_PFILL(1, 1);
-    __syncthreads();                                           // stage 0 (and 1) of the first item has landed
-    for (;;) {
-      W4_TRANSFORM(0, 0, );
-      __syncthreads();
-      for (int g = 0; g < nsteps; ++g) {
-        if (g + 1 < nsteps) {
-          if ((g & 1) == 0) W4_TRANSFORM(1, 1, if (g + 2 < nsteps) W4_PFILL(0, g + 2)); else W4_TRANSFORM(0, 0, if (g + 2 < nsteps) W4_PFILL(1, g + 2));
-        }
-        __syncthreads();
-      }
-      // the consumers' output transform goes through the V buffers: the patch buffers take the next item's first two stages now
-      const int next = item + Gn;
-      if (next < nitems) {
-        W4_PSETUP(next);
-        W4_PFILL(0, 0);
-        if (nsteps > 1) W4_PFILL(1, 1);
-      }
-      __syncthreads();                                         // B1: round A written
-      __syncthreads();                                         // B2: round A read
-      __syncthreads();                                         // B3: round B written
-      __syncthreads();                                         // B4: round B read -- and (the fence) this wave's DMA has landed
-      if (next >= nitems) break;
-      item = next;
-    }
-#undef W4_PSETUP
-#undef W4_PFILL
-#undef W4_TRANSFORM
-    return;
-  }
-
-  // ---- consumers ---------------------------------------------------------------------------------------------------------------
-  const int xi = wave >> 1, hh = wave & 1;
-  const int f0 = xi * 6 + 3 * hh;
-  const int w_off = f0 * 1024 + lane * 16;
-  const int v_off = f0 * 1024 + l31 * 32 + half * 16;
-  f32x16 acc[3];
-#pragma unroll
-  for (int n = 0; n < 3; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-  float4 wq[2], vq[2];
-#define W4_LOADOP(SET, N, STEP, VP)                                                                  \
-  do {                                                                                              \
-    vq[SET] = *reinterpret_cast<const float4*>((VP) + (N) * 1024);                                  \
-    wq[SET] = w4_f4(__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_off + (N) * 1024, (STEP) * 36864, 0)); \
-  } while (0)
-#define W4_LOADW(SET, N, STEP) wq[SET] = w4_f4(__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_off + (N) * 1024, (STEP) * 36864, 0))
-#define W4_MFMAS(SET, N)                                                                             \
-  do {                                                                                              \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                   \
-      acc[N] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4_e(wq[SET], t), w4_e(vq[SET], t), acc[N], 0, 0, 0); \
-  } while (0)
-#define W4_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
-  W4_BARRIER();                                                // the first item's stages 0 / 1 have landed
-  for (;;) {
-    W4_DECODE(item);
-    (void)b_first; (void)ty_first;
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.u) + (size_t)nb * nsteps * 9216, 0, (int)0x80000000u, 0x00020000);
-    W4_LOADW(0, 0, 0);
-    W4_BARRIER();                                              // V of stage 0 is written
-    vq[0] = *reinterpret_cast<const float4*>(sV + v_off);
-    for (int g = 0; g < nsteps; ++g) {
-      const int gn = g + 1 < nsteps ? g + 1 : g;
-      const char* vp = sV + (g & 1) * W4_VBUF + v_off;
-      W4_LOADOP(1, 1, g, vp);
-      __builtin_amdgcn_sched_barrier(0);
-      W4_MFMAS(0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      W4_LOADOP(0, 2, g, vp);
-      __builtin_amdgcn_sched_barrier(0);
-      W4_MFMAS(1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      W4_LOADW(1, 0, gn);
-      __builtin_amdgcn_sched_barrier(0);
-      W4_MFMAS(0, 2);
-      __builtin_amdgcn_sched_barrier(0);
-      W4_BARRIER();
-      vq[1] = *reinterpret_cast<const float4*>(sV + ((g + 1) & 1) * W4_VBUF + v_off);
-      if (++g >= nsteps) break;
-      const int gn2 = g + 1 < nsteps ? g + 1 : g;
-      const char* vp2 = sV + (g & 1) * W4_VBUF + v_off;
-      W4_LOADOP(0, 1, g, vp2);
-      __builtin_amdgcn_sched_barrier(0);
-      W4_MFMAS(1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      W4_LOADOP(1, 2, g, vp2);
-      __builtin_amdgcn_sched_barrier(0);
-      W4_MFMAS(0, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      W4_LOADW(0, 0, gn2);
-      __builtin_amdgcn_sched_barrier(0);
-      W4_MFMAS(1, 2);
-      __builtin_amdgcn_sched_barrier(0);
-      W4_BARRIER();
-      vq[0] = *reinterpret_cast<const float4*>(sV + ((g + 1) & 1) * W4_VBUF + v_off);
-    }
-    // A^T M A, first half (see conv_wino4_f32_kernel), then two exchange rounds of 16 channels through V[0] / V[1]
-    if (hh == 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float s_ = acc[1][r] + acc[2][r], d_ = acc[1][r] - acc[2][r];
-        acc[0][r] = acc[0][r] + s_; acc[1][r] = d_; acc[2][r] = s_;
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float s_ = acc[0][r] + acc[1][r], d_ = acc[0][r] - acc[1][r];
-        acc[0][r] = s_; acc[1][r] = d_;
-      }
-    }
-#pragma unroll
-    for (int round = 0; round < 2; ++round) {
-#pragma unroll
-      for (int rl = 0; rl < 2; ++rl)
-#pragma unroll
-        for (int n = 0; n < 3; ++n)
-          *reinterpret_cast<float4*>(sV + rl * W4_VBUF + v_off + n * 1024) =
-              make_float4(acc[n][8 * round + 4 * rl + 0], acc[n][8 * round + 4 * rl + 1], acc[n][8 * round + 4 * rl + 2],
-                          acc[n][8 * round + 4 * rl + 3]);
-      __syncthreads();                                         // B1 / B3
-      if (wave < 8) w4_output_pass<D, LINEAR, VSH>(a, sV, wave, lane, nb, R0, s0, tx0, 16 * round);
-      __syncthreads();                                         // B2 / B4
-    }
-#pragma unroll
-    for (int n = 0; n < 3; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-    item += Gn;
-    if (item >= nitems) break;
-  }
-#undef W4_LOADOP
-#undef W4_LOADW
-#undef W4_MFMAS
-#undef W4_BARRIER
-#undef W4_DECODE
-}
-
 }  // namespace
 
 static int w4_device_cus() {
@@ -731,12 +482,6 @@ static int w4_device_cus() {
     cus[dev].store(n, std::memory_order_relaxed);
   }
   return n;
-}
-
-// developer switch (tests run both forms and compare bits): HANDS_WINO4_PERSISTENT=0 launches one workgroup per item
-static bool w4_env_persistent() {
-  static const bool v = [] { const char* e = getenv("HANDS_WINO4_PERSISTENT"); return !(e && e[0] == '0'); }();
-  return v;
 }
 
 static void w4_magic(int d, uint32_t& mul, uint32_t& sh) {
@@ -773,11 +518,6 @@ static int w4_launch_nob(Wino4Args& a, hipStream_t stream) {
   w4_magic(a.nh, a.nh_mul, a.nh_sh);
   const long long imgs = G::NR / a.nh + 2;
   if (imgs * a.H * a.W * a.in_ps * 4 >= 0x7fffffffLL) return HANDS_EINVAL;
-  if (NOB == 1 && w4_env_persistent()) {       // one workgroup per CU walks the items (same arithmetic, same bits)
-    const long long g = nwg < w4_device_cus() ? nwg : w4_device_cus();
-    hipLaunchKernelGGL((conv_wino4p_f32_kernel<D, LINEAR, VSH>), dim3((unsigned)g), dim3(1024), 0, stream, a);
-    return (int)hipGetLastError();
-  }
   hipLaunchKernelGGL((conv_wino4_f32_kernel<D, LINEAR, VSH, NOB>), dim3((unsigned)nwg), dim3(1024), 0, stream, a);
   return (int)hipGetLastError();
 }
