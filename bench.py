@@ -216,7 +216,7 @@ def same_run_pmc(args, workload, bz):
                    os.path.abspath(__file__), "--pmc-child", "--workload", workload, "--bz", str(bz)]
             try:
                 p = subprocess.run(cmd, env=env, cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
-                                   timeout=float(os.environ.get("HANDS_PMC_TIMEOUT", "300")))
+                                   timeout=float(os.environ.get("HANDS_PMC_TIMEOUT", "150")))
             except subprocess.TimeoutExpired:
                 return {"error": f"{counter} pass timed out"}
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
@@ -1041,7 +1041,7 @@ def main():
         from hands_amd.dist import allgather_selfcheck
         try:
             selfcheck = allgather_selfcheck("cpu" if ctx.host_collective else ctx.dev,
-                                            timeout_s=float(os.environ.get("HANDS_SELFCHECK_TIMEOUT", "20")))
+                                            timeout_s=float(os.environ.get("HANDS_SELFCHECK_TIMEOUT", "180")))
         except RuntimeError as e:
             sys.stderr.write(str(e) + "\n")
             sys.stderr.flush()

@@ -158,7 +158,7 @@ def data_parallel_forward(model, inputs, meta_info, group=None, gather_on_host=F
 PACKED_WIDTH = 5171      # fp32 columns of one packed sample pair (the 22 prediction tensors of a forward)
 
 
-def allgather_selfcheck(device, rows: int = 32, width: int = PACKED_WIDTH, timeout_s: float = 20.0, group=None,
+def allgather_selfcheck(device, rows: int = 32, width: int = PACKED_WIDTH, timeout_s: float = 180.0, group=None,
                         _corrupt: bool = False) -> dict:
     """First-contact check of the prediction all-gather on the layout the forward uses (one ``(rows, width)`` fp32 buffer per
     rank, ``all_gather_into_tensor`` -- RCCL on the GPU box, gloo in the CPU test): every rank fills its buffer with a pattern
@@ -166,13 +166,16 @@ def allgather_selfcheck(device, rows: int = 32, width: int = PACKED_WIDTH, timeo
 
     A collective that never returns (a peer died, a link is down) cannot be cancelled from Python, so a watchdog thread ends
     this process with exit code 3 after ``timeout_s``; a mismatch raises ``RuntimeError`` (bench.py exits with code 4).  No
-    process is re-executed.  Returns ``{"ranks", "us", "rows", "width"}`` -- ``us`` = wall time of the checked collective."""
+    process is re-executed.  The window is generous (default 180 s) because this is the job's FIRST collective: RCCL builds its
+    communicator and transports inside it (seconds on a cold 8-GPU node); a small warm-up all-gather runs first, so ``us`` --
+    the wall time of the checked collective in the returned ``{"ranks", "us", "first_contact_s", "rows", "width"}`` -- is a warm
+    figure and ``first_contact_s`` shows what the set-up cost."""
     import os
     import sys
     import threading
     import time
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return {"ranks": 1, "us": 0.0, "rows": rows, "width": width}
+        return {"ranks": 1, "us": 0.0, "first_contact_s": 0.0, "rows": rows, "width": width}
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     dev = torch.device(device)
 
@@ -196,8 +199,12 @@ def allgather_selfcheck(device, rows: int = 32, width: int = PACKED_WIDTH, timeo
         if _corrupt:
             mine[rows // 2, width // 2] += 1.0
         full = torch.empty((world * rows, width), dtype=torch.float32, device=dev)
+        tc = time.perf_counter()
+        warm = [torch.empty(8, dtype=torch.float32, device=dev) for _ in range(world)]
+        dist.all_gather(warm, torch.full((8,), float(rank), dtype=torch.float32, device=dev), group=group)   # first contact
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
+        first_contact_s = time.perf_counter() - tc
         t0 = time.perf_counter()
         single = _single_buffer_gather.get((dist.get_backend(group), dev.type), True)
         if single:
@@ -222,4 +229,4 @@ def allgather_selfcheck(device, rows: int = 32, width: int = PACKED_WIDTH, timeo
     if bad:
         raise RuntimeError(f"hands_amd.dist.allgather_selfcheck: rank {rank} of {world}: the segments of rank(s) {bad} arrived "
                            f"corrupted ({rows} x {width} fp32 per rank, backend {dist.get_backend(group)})")
-    return {"ranks": world, "us": round(us, 1), "rows": rows, "width": width}
+    return {"ranks": world, "us": round(us, 1), "first_contact_s": round(first_contact_s, 3), "rows": rows, "width": width}
