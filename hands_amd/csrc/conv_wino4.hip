@@ -303,7 +303,11 @@ __global__ void __launch_bounds__(1024, 1) conv_wino4_f32_kernel(Wino4Args a) {
     for (int g = 0; g < nsteps; ++g) {
       W4_STAMP(1, 2 + 3 * g);
 #if !(defined(W4_ABL) && W4_ABL == 2)       // timing-only ablation (tools/build_variant.sh, EXTRA_FLAGS=-DW4_ABL=n): 2 = no transform in the loop
+#if defined(W4_ABL) && W4_ABL == 5           // 5 = fill + transform in every other pair of stages only: the producer load per MFMA that
+      if (g + 1 < nsteps && (g & 2) == 0) { //     64 output channels per workgroup would have
+#else
       if (g + 1 < nsteps) {
+#endif
         // (the patch buffer of stage g was transformed during stage g - 1: stage g + 2 may land in it)
         if ((g & 1) == 0) W4_TRANSFORM(1, 1, if (g + 2 < nsteps) W4_PFILL(0, g + 2)); else W4_TRANSFORM(0, 0, if (g + 2 < nsteps) W4_PFILL(1, g + 2));
       }

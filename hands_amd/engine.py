@@ -51,6 +51,7 @@ class ConvEngine:
                                       # A fixed function of the layer -- batch-size independent.  HandOccNet sets it (DESIGN.md
                                       # "Conditioning note"); 0 elsewhere
         self.chain_min_k = 0          # launches with Kpad below max(chain_min_k, 2 * chain_limit) keep their single chain
+        self.chain_skip_tokens = False  # True: token GEMMs (H = W = 1 with >= 4096 rows: the transformer MLPs) keep their single chain
         self.chain_max_pix = 0        # > 0: only launches on maps of at most this many output pixels per image are blocked (the
                                       # workspace round trip is per output element: large maps pay most for the same chain)
         self.hook = None              # callable(phase, pc, npix, stream_handle, has_res, kernel): bench.py brackets
@@ -68,7 +69,7 @@ class ConvEngine:
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
         for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "winograd", "winograd4", "fuse_mano", "fuse_pre", "stream_k", "math", "chain_limit",
-                  "chain_min_k", "chain_max_pix"):
+                  "chain_min_k", "chain_max_pix", "chain_skip_tokens"):
             setattr(e, k, getattr(self, k))
         return e
 
@@ -166,7 +167,8 @@ class ConvEngine:
             return Ho, Wo
         if (self.chain_limit and self.use_splitk and self.math == "fp32"
                 and pc.Kpad >= max(2 * self.chain_limit, self.chain_min_k)
-                and (not self.chain_max_pix or Ho * Wo <= self.chain_max_pix)):
+                and (not self.chain_max_pix or Ho * Wo <= self.chain_max_pix)
+                and not (self.chain_skip_tokens and H * W == 1 and B >= 4096)):
             # blocked summation (not the Winograd launches above: their chains are Cin long)
             S = max(S, min(pc.Kpad // self.chain_limit, 32))
         if pre is not None:

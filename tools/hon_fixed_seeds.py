@@ -24,11 +24,12 @@ base = hands_amd.apply_recipe(hands_amd.HandOccNet())
 sd = {k: v.clone() for k, v in base.state_dict().items()}
 models = {}
 for name in arms:
-    scope, limit, min_k, max_pix = parse_arm(name)
+    scope, limit, min_k, max_pix, skip_tok = parse_arm(name)
     m = hands_amd.apply_recipe(hands_amd.HandOccNet()).to("cuda").eval()
     m.engine.winograd = scope != "direct"
     m.winograd_scope = scope if scope != "direct" else "backbone"
     m.engine.chain_limit, m.engine.chain_min_k, m.engine.chain_max_pix = limit, min_k, max_pix
+    m.engine.chain_skip_tokens = skip_tok
     m.invalidate_packed()
     m.async_forward = False
     models[name] = m
