@@ -764,7 +764,34 @@ def parity_sweep(ctx, workload, model, sd_cpu):
         e = parity_vs_oracle(ctx, workload, model, sd_cpu, cb, sample=sample)["max_vertex_err_m"]
         if e >= worst:
             worst, worst_seed = e, seed
-    return {"worst_vertex_err_m": float(f"{worst:.3e}"), "worst_seed": worst_seed, "sweep_seeds": len(seeds), "bar_m": 1e-6}
+    res = {"worst_vertex_err_m": float(f"{worst:.3e}"), "worst_seed": worst_seed, "sweep_seeds": len(seeds), "bar_m": 1e-6}
+    res.update(stored_exceed_rate(workload, model))
+    return res
+
+
+def stored_exceed_rate(workload, model):
+    """handoccnet_light: the share of random inputs whose max vertex error against the reference exceeds 1e-6 m, from the committed
+    1000-seed A/B of the setting this model runs (profiles/r05_hon_parity_ab_1000seeds*_summary.json, tools/hon_parity_ab.py) -- a
+    STORED figure (the run takes 2 minutes of CPU forwards), named as such; absent for any other setting."""
+    if workload != "handoccnet_light" or not hasattr(model, "winograd_scope"):
+        return {}
+    e = model.engine
+    arm = model.winograd_scope if e.winograd else "direct"
+    if e.chain_limit:
+        arm += f"+c{e.chain_limit}"
+        if e.chain_min_k and e.chain_min_k != 2 * e.chain_limit:
+            arm += f"k{e.chain_min_k}"
+    for fn in ("r05_hon_parity_ab_1000seeds_summary.json", "r05_hon_parity_ab_1000seeds_b_summary.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            a = d["arms"].get(arm)
+            if a:
+                return {"exceed_rate": round(a["exceed_rate"], 4), "exceed_wilson95": [round(v, 4) for v in a["wilson95"]],
+                        "exceed_n": d["n"], "median_err_ratio_vs_fp64": round(a["median_ratio_hip64_over_ref64"], 2),
+                        "exceed_source": f"stored: profiles/{fn} arm {arm}"}
+        except (OSError, ValueError, KeyError):
+            continue
+    return {}
 
 
 def cpu_baseline_hands_light(ctx, model, sd_cpu):
@@ -935,7 +962,8 @@ ROOFLINE_KEYS = ("bound", "mode", "kernel", "achieved", "peak", "unit", "frac", 
                  "step_ms_same_mode",
                  "launches_per_step", "us_per_launch", "device_ms_per_step", "hbm_gbs")
 CPU_KEYS = ("value", "unit", "cores", "kind", "bz", "sample")
-PARITY_KEYS = ("mpjpe_vs_ref_mm", "max_vertex_err_m", "checked_hands", "worst_vertex_err_m", "worst_seed", "sweep_seeds", "bar_m")
+PARITY_KEYS = ("mpjpe_vs_ref_mm", "max_vertex_err_m", "checked_hands", "worst_vertex_err_m", "worst_seed", "sweep_seeds", "bar_m",
+               "exceed_rate", "exceed_wilson95", "exceed_n", "median_err_ratio_vs_fp64", "exceed_source")
 CONFIG_KEYS = ("workload", "per_gpu_batch", "global_batch", "parallelism", "rccl_ranks", "collective_backend", "launched_by",
                "timed_mode", "conv3x3_stride1", "steps", "warmup", "allgather_selfcheck_us")
 
