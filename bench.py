@@ -65,9 +65,10 @@ def parse_args(argv=None):
                     help="time the one-stream mode as the headline too (every launch alone on the chip)")
     ap.add_argument("--latency-mode", action="store_true",
                     help="small-batch serving mode: split-K on every launch with <= 128 output tiles")
-    ap.add_argument("--graph", type=int, default=0, metavar="DEPTH",
-                    help="replay the forward as a hipGraph (hands_amd.GraphedForward); DEPTH=2 keeps two captured instances "
-                         "in flight (handoccnet_light only)")
+    ap.add_argument("--graph", type=int, default=-1, metavar="DEPTH",
+                    help="replay the forward as a hipGraph (hands_amd.GraphedForward); DEPTH > 1 keeps that many captured instances "
+                         "in flight (handoccnet_light only).  Default: 4 for --workload handoccnet_light at N > 1 (its fastest "
+                         "bit-identical mode at the 8-GPU shard size; config.timed_mode says so), eager otherwise; 0 forces eager")
     ap.add_argument("--layer-report", default="", help="write a per-launch CSV of the MFMA kernels here")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not take the same-run rocprofv3 --pmc passes (roofline.traffic then comes from a stored summary)")
@@ -524,7 +525,13 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         if ctx.host_collective:                   # dry-run only: gloo gathers host tensors
             torch.cuda.synchronize(ctx.dev)
             return gather_predictions({k: v.cpu() for k, v in out.items()})
-        return gather_predictions(out) if ctx.world > 1 else out
+        if ctx.world == 1:
+            return out
+        g = gather_predictions(out)
+        if graph and getattr(g, "is_pending", False):
+            # the gather packs the captured instance's STATIC outputs on a side stream: its next replay waits for that
+            fwd.hold_until(g.__dict__["_ready"])
+        return g
 
     elapsed = ctx.timed(step, steps, warmup)
     enqueue_ms = host_enqueue_ms(ctx, step)
@@ -1048,6 +1055,8 @@ def main():
     if args.pmc_child:
         return pmc_child(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.graph < 0:                         # auto: the fastest bit-identical mode of config 4's shard size
+        args.graph = 4 if (args.workload == "handoccnet_light" and world > 1 and not args.serial and not args.latency_mode) else 0
     if (world == 1 and args.workload != "mano_lbs" and not args.no_pmc and not args.latency_mode and not args.graph
             and not os.environ.get("HANDS_BENCH_PMC_CHILD") and not os.environ.get("ROCPROFILER_LIBRARY_CTOR")
             and "rocprof" not in os.environ.get("LD_PRELOAD", "") and not os.environ.get("HANDS_BENCH_SHIPPED_ONLY")):

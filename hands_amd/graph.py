@@ -40,6 +40,8 @@ class GraphedForward:
         self._tokens = []
         self.static_in, self.static_meta, self.static_out, self.graphs = [], [], [], []
         self._done = [None] * self.depth          # event of the last replay of instance i (pipelined mode)
+        self._hold = [None] * self.depth          # event behind which instance i's static outputs are still being read
+        self._last = 0
         self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.depth)] if self.depth > 1 else []
         side = torch.cuda.Stream(device=dev)
         for i in range(self.depth):
@@ -75,6 +77,10 @@ class GraphedForward:
         clone what must survive the next ``depth`` calls.  depth > 1: the result is a `stream_xdict` joined at
         its first use; the caller may overwrite its inputs as soon as this returns."""
         i = self._calls % self.depth
+        if self._hold[i] is not None:             # a consumer registered with hold_until() still reads this instance's outputs
+            torch.cuda.current_stream(self.dev).wait_event(self._hold[i])
+            self._hold[i] = None
+        self._last = i
         if self.depth == 1:
             self._load(self.static_in[0], inputs)
             self._load(self.static_meta[0], meta_info)
@@ -97,6 +103,12 @@ class GraphedForward:
             ready.record(st)
         self._done[i] = ready
         return stream_xdict(self.static_out[i], ready, self.dev)
+
+    def hold_until(self, event):
+        """The (static) outputs returned by the LAST call are read asynchronously -- e.g. packed and all-gathered on a side stream
+        (`hands_amd.dist.gather_predictions` of a pending result) -- until ``event``: the next replay of that captured instance,
+        ``depth`` calls from now, waits for it instead of overwriting them under the reader."""
+        self._hold[self._last] = event
 
     def synchronize(self):
         for ev in self._done:

@@ -154,3 +154,5 @@ def test_bench_strong_scaling_dry_runs(workload, global_bz):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rccl_ranks"] == 2
     assert d["config"]["global_batch"] == global_bz and d["config"]["per_gpu_batch"] == global_bz // 2
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
+    if workload == "handoccnet_light":           # N > 1: the hipGraph replay with four captured forwards in flight is the timed mode
+        assert "hipgraph(depth=4)" in d["config"]["timed_mode"], d["config"]
