@@ -5,15 +5,18 @@ Same constructor, ``forward(inputs, meta_info) -> xdict`` contract, 22 output ke
 statement of ``forward`` runs as a hand-written gfx950 kernel from ``libhands_hip.so``:
 
     statement (model.py)                      kernel (include/hands_hip.h)
-    :193,238-239  ResNet-50 trunks            hands_conv2d_nhwc_f32 (fp32 MFMA implicit GEMM, BN folded,
-                                              bias/residual/ReLU epilogue), hands_maxpool3x3s2_nhwc_f32
+    :193,238-239  ResNet-50 trunks            hands_stem_conv_maxpool_nchw_f32 (conv1 + bn1 + relu + max-pool from the NCHW image),
+                                              hands_conv2d_nhwc_f32 / hands_conv1x1_dual_nhwc_f32 (fp32 MFMA implicit GEMM, BN
+                                              folded, bias / residual / ReLU epilogue), hands_conv3x3_winograd4_f32 (the 3x3 /
+                                              stride-1 layers as Winograd F(4x4,3x3); hands_conv3x3_winograd_f32 = F(2x2) fallback)
     :196          sum-pool                    hands_sumpool_nhwc_f32
     :258-271      KPE + concat                hands_kpe_concat_f32
     :313-314      feature_conv                hands_conv2d_nhwc_f32 x4
     :320-321      HandHMR x2                  hands_conv2d_nhwc_f32 (cam_init, 3 x refine+decoders),
                                               hands_hmr_init_f32, hands_rot6d_to_matrix_f32
     :341-368      is_flipped swap             hands_flip_swap_f32 (per sample, no host sync)
-    :378-390      MANOHead x2                 hands_mano_pose_f32, blend GEMM, hands_mano_skin_f32
+    :378-390      MANOHead x2                 hands_mano_heads_f32 (both hands, one launch; the three-launch chain
+                                              hands_mano_pose_f32 -> blend GEMM -> hands_mano_skin_f32 is its cross-check)
     :401-404      grasp classifier            hands_grasp_input_f32, hands_conv2d_nhwc_f32 x4
 
 torch is used for parameter containers, device buffers and streams only.  Built configurations: resnet50,
