@@ -107,7 +107,10 @@ class HandOccNet(EngineSwitches, nn.Module):
         self.async_forward = True   # two forwards in flight: call i runs on pipeline stream i & 1 and is joined at the first
                                     # use of its result (stream_xdict), so the launches of consecutive calls fill each other's
                                     # tails -- at 32 samples per GPU a launch is 1-4 tiles per CU, all in phase when alone
-        self.pipeline_depth = 2     # forwards in flight in the pipelined mode (3 and 4 measured: see profiles/README.md)
+        self.pipeline_depth = "auto"  # forwards in flight in the pipelined mode: an int, or "auto" = 3 up to 64 samples per call, 2
+                                    # above (round 5, one box, alternating: 32 samples 3833-3844 hands/s with 3 against 3738 with 2
+                                    # and 3755 with 4; 256 samples 3786-3808 with 3 against 3832-3838 with 2) -- a launch schedule,
+                                    # the arithmetic of a forward does not depend on it
         self._calls = 0
         self._pipe_done = {}
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_packed())
@@ -274,7 +277,8 @@ class HandOccNet(EngineSwitches, nn.Module):
         capturing = self.engine._capturing(L, main.cuda_stream)
         pipelined = bool(self.async_forward and self.engine.overlap and dbg is None and self.engine.hook is None and not capturing)
         if pipelined:
-            par = self._calls % max(1, int(self.pipeline_depth))
+            depth = (3 if bz <= 64 else 2) if self.pipeline_depth == "auto" else max(1, int(self.pipeline_depth))
+            par = self._calls % depth
             self._calls += 1
             st = self._side_stream(dev, f"pipe{par}")
             K = K.clone()

@@ -181,6 +181,32 @@ def test_handoccnet_batch_independence(hon_gpu):
         assert torch.equal(big[k][:2], small[k]), k
 
 
+def test_handoccnet_pipelined_forwards_keep_stream_semantics(hon_gpu):
+    """HandOccNet.async_forward (default): call i runs on pipeline stream i % depth (three forwards in flight at this size) and
+    is joined at the first use of its result.  Five un-consumed forwards in flight, the caller zeroing its inputs right after
+    every call: each result equals the synchronous forward of ITS inputs bit for bit."""
+    samples = [synthetic_inputs(2, seed, device=DEV) for seed in (0, 3, 5, 9, 11)]
+    hon_gpu.async_forward = False
+    try:
+        sync = [{k: v.clone() for k, v in hon_gpu(i, m).items()} for i, m in samples]
+    finally:
+        hon_gpu.async_forward = True
+    torch.cuda.synchronize()
+    assert hon_gpu.pipeline_depth == "auto"
+    pending = []
+    for inputs, meta_info in samples:
+        mine = ({k: v.clone() for k, v in inputs.items()}, {k: v.clone() for k, v in meta_info.items()})
+        out = hon_gpu(*mine)
+        assert out.is_pending
+        for d in mine:
+            for v in d.values():
+                v.zero_()
+        pending.append(out)
+    for out, ref in zip(pending, sync):
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), k
+
+
 def test_graphed_handoccnet_hold_until_protects_an_asynchronous_reader(hon_gpu):
     """`bench.py --workload handoccnet_light --gpus N` replays captured forwards (depth 4) and all-gathers their STATIC outputs on a
     side stream (hands_amd.dist.gather_predictions of a pending result).  GraphedForward.hold_until(event) makes the next replay of
