@@ -1143,7 +1143,7 @@ def main():
             try:
                 math, wino, wscope, graph = "fp32", None, None, 0
                 mg = re.search(r"_graph(\d+)$", name)   # hands_amd.GraphedForward(depth=N): N captured forwards in flight
-                if mg:                                   # (depth 2 / 3 / 4 / 6 measured 3617 / 3670 / 3703 / 3752 hands/s, eager 3657)
+                if mg:                                   # (round 5: depth 3 / 4 / 6 3736 / 3790 / 3753 hands/s, eager with three in flight 3870)
                     name, graph = name[: mg.start()], int(mg.group(1))
                 if name.endswith("_backbone_unblocked"):
                     name, wino, wscope = name[: -len("_backbone_unblocked")], True, "backbone"
