@@ -1136,9 +1136,9 @@ def main():
         # name, bz, steps, warmup, parity bz.  *_bf16x3: separately reported arithmetic mode, never the headline value;
         # *_backbone_unblocked: HandOccNet's default of rounds 3-4 (Winograd in the backbone only, single fp32 chains), for comparison
         for name, abz, asteps, awarm, pbz in (("hands_light_bf16x3", 256, 10, 3, 8), ("hamer_light", 64, 4, 1, 1),
-                                              ("hamer_light_bf16x3", 64, 4, 1, 1), ("handoccnet_light", 32, 10, 3, 2),
-                                              ("handoccnet_light_graph4", 32, 12, 4, 2),
-                                              ("handoccnet_light_backbone_unblocked", 32, 10, 3, 2)):
+                                              ("hamer_light_bf16x3", 64, 4, 1, 1), ("handoccnet_light", 32, 30, 8, 2),
+                                              ("handoccnet_light_graph4", 32, 32, 8, 2),
+                                              ("handoccnet_light_backbone_unblocked", 32, 30, 8, 2)):
             key = name
             try:
                 math, wino, wscope, graph = "fp32", None, None, 0
