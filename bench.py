@@ -497,7 +497,7 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         model.engine.fuse_pre = os.environ["HANDS_FUSE_PRE"] == "1"
     if winograd is not None:                       # the model's own default otherwise
         model.engine.winograd = bool(winograd)
-    if winograd_scope is not None and hasattr(model, "winograd_scope"):    # HandOccNet: default "all" + chains <= 256 floats
+    if winograd_scope is not None and hasattr(model, "winograd_scope"):    # HandOccNet: default "all" + chains <= 128 floats
         model.winograd_scope = winograd_scope
         if winograd_scope == "backbone":           # the comparison line: rounds 3-4's default, single fp32 chains
             model.engine.chain_limit = 0
@@ -788,7 +788,10 @@ def stored_exceed_rate(workload, model):
         arm += f"+c{e.chain_limit}"
         if e.chain_min_k and e.chain_min_k != 2 * e.chain_limit:
             arm += f"k{e.chain_min_k}"
-    for fn in ("r05_hon_parity_ab_1000seeds_summary.json", "r05_hon_parity_ab_1000seeds_b_summary.json"):
+        if getattr(e, "chain_in_kernel", False):
+            arm += "i"
+    for fn in ("r05_hon_parity_ab_1000seeds_d_summary.json", "r05_hon_parity_ab_1000seeds_summary.json",
+               "r05_hon_parity_ab_1000seeds_b_summary.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", fn)))
             a = d["arms"].get(arm)
@@ -1044,7 +1047,8 @@ def conv3x3_route(model):
     if getattr(model.engine, "winograd4", False) and getattr(model, "winograd4_stages", ()):
         return "winograd_f4x4:stages" + "".join(str(i) for i in model.winograd4_stages)     # (F(2x2) where F(4x4) is not packed)
     return ("winograd_f2x2" + (f":{model.winograd_scope}" if hasattr(model, "winograd_scope") else "")
-            + (f"+chains<={model.engine.chain_limit}" if getattr(model.engine, "chain_limit", 0) else ""))
+            + (f"+chains<={model.engine.chain_limit}" + ("(in-kernel)" if getattr(model.engine, "chain_in_kernel", False) else "")
+               if getattr(model.engine, "chain_limit", 0) else ""))
 
 
 def main():

@@ -185,7 +185,10 @@ constexpr int SK_SLOT_FLOATS = 4 * 64 * 64;   // one workgroup's accumulators: 4
 // both operands are split on the way into LDS into three bf16 planes whose sum is the fp32 value exactly, and a
 // k-16 step is six v_mfma_f32_32x32x16_bf16 (the products b_i * b_j with i + j <= 2, fp32 accumulation): the
 // dropped terms are <= 2^-24 of a product -- fp32-grade results at 3/8 of the matrix-pipe time.
-template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool PRE = false>
+// BLK > 0 (8 or 4 k-steps = 128 / 64 floats): blocked summation -- after every BLK k-steps the accumulators are added to a
+// second set and cleared, so no fp32 FMA chain is longer than the block (HANDS_SUM_BLOCK*; 64 more registers: these
+// instantiations run two workgroups per CU instead of four).
+template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool PRE = false, int BLK = 0>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int tile, int split, int kt0, int kt1,
                                           const float* acc_in, float* acc_out) {
   constexpr int ROW = PREC ? LDS_ROW_B3 : LDS_ROW;
@@ -479,15 +482,43 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
     }                                                                                               \
   } while (0)
 
+  static_assert(BLK == 0 || ((BLK & (BLK - 1)) == 0 && PREC == 0), "block length: a power of two k-steps, exact fp32 only");
+  f32x16 tot[BLK ? 2 : 1][BLK ? 2 : 1];
+  if constexpr (BLK > 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+  }
   // steady state: loads of step kt+1 are in flight under the 32 MFMAs of step kt
   for (int kt = kt0; kt + 1 < kt1; ++kt) {
     const int buf = (kt - kt0) & 1;
     LOAD_TILES(kt + 1);
     COMPUTE_STEP(buf);
+    if constexpr (BLK > 0) {
+      if (((kt - kt0 + 1) & (BLK - 1)) == 0) {          // (uniform) end of a block: its sum joins the total, in block order
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
+      }
+    }
     STORE_TILES(buf ^ 1);
     __syncthreads();
   }
   COMPUTE_STEP((kt1 - 1 - kt0) & 1);
+  if constexpr (BLK > 0) {                                // the last (possibly partial) block
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += tot[i][j][r];
+  }
 #undef COMPUTE_STEP
 
   // ---- epilogue -------------------------------------------------------------------------------------
@@ -580,7 +611,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
 #undef STORE_TILES
 }
 
-template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool PRE = false>
+template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool PRE = false, int BLK = 0>
 __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   constexpr int RING = 2 * (64 * WAVES_M + 64 * WAVES_N) * (PREC ? LDS_ROW_B3 : LDS_ROW);
   __shared__ __attribute__((aligned(16))) float lds[RING > EPI_FLOATS ? RING : EPI_FLOATS];
@@ -591,7 +622,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   const int nk_all = a.Kpad / BK;
   const int kt0 = a.ksplit > 1 ? (int)((long long)split * nk_all / a.ksplit) : 0;
   const int kt1 = a.ksplit > 1 ? (int)((long long)(split + 1) * nk_all / a.ksplit) : nk_all;
-  conv_tile<WAVES_M, WAVES_N, MODE, PREC, PRE>(a, lds, tile, split, kt0, kt1, nullptr, nullptr);
+  conv_tile<WAVES_M, WAVES_N, MODE, PREC, PRE, BLK>(a, lds, tile, split, kt0, kt1, nullptr, nullptr);
 }
 
 // ---- stream-K: persistent workgroups with equal shares of (tile, k-step) units -------------------------------
@@ -676,16 +707,25 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_sk_f32_kernel(ConvArgs a, S
   }
 }
 
-template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool PRE = false>
+template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool PRE = false, int BLK = 0>
 int launch(ConvArgs& a, hipStream_t stream) {
   constexpr int BM = 64 * WAVES_M, BN = 64 * WAVES_N;
   a.nblk_m = (a.M + BM - 1) / BM;
   a.nblk_n = (a.N + BN - 1) / BN;
   const long long nwg = (long long)a.nblk_m * a.nblk_n * (a.ksplit > 1 ? a.ksplit : 1);
   if (nwg <= 0 || nwg > 0x7fffffffLL) return HANDS_EINVAL;
-  hipLaunchKernelGGL((conv_igemm_f32_kernel<WAVES_M, WAVES_N, MODE, PREC, PRE>), dim3((unsigned)nwg), dim3(256), 0,
+  hipLaunchKernelGGL((conv_igemm_f32_kernel<WAVES_M, WAVES_N, MODE, PREC, PRE, BLK>), dim3((unsigned)nwg), dim3(256), 0,
                      stream, a);
   return (int)hipGetLastError();
+}
+
+// exact-fp32 launch of MODE (0 any convolution, 2 pointwise) with the summation block the descriptor asks for
+template <int MODE, bool PRE = false>
+int launch_fp32(const hands_conv_desc* d, ConvArgs& a, hipStream_t s) {
+  const bool narrow = d->Cout <= 64;
+  if (d->act & HANDS_SUM_BLOCK128) return narrow ? launch<4, 1, MODE, 0, PRE, 8>(a, s) : launch<2, 2, MODE, 0, PRE, 8>(a, s);
+  if (d->act & HANDS_SUM_BLOCK64) return narrow ? launch<4, 1, MODE, 0, PRE, 4>(a, s) : launch<2, 2, MODE, 0, PRE, 4>(a, s);
+  return narrow ? launch<4, 1, MODE, 0, PRE>(a, s) : launch<2, 2, MODE, 0, PRE>(a, s);
 }
 
 constexpr int SK_MAX_G = 1024;
@@ -797,7 +837,9 @@ bool conv_geometry_ok(const hands_conv_desc* d) {
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 ||
       d->pad < 0)
     return false;
-  if ((d->act & HANDS_ACT_MASK) > HANDS_ACT_LEAKY_RELU || (d->act & ~(HANDS_ACT_MASK | HANDS_MATH_BF16X3))) return false;   // unknown code
+  if ((d->act & HANDS_ACT_MASK) > HANDS_ACT_LEAKY_RELU || (d->act & ~(HANDS_ACT_MASK | HANDS_MATH_BF16X3 | HANDS_SUM_BLOCK128 | HANDS_SUM_BLOCK64))) return false;   // unknown code
+  if ((d->act & HANDS_SUM_BLOCK128) && (d->act & (HANDS_SUM_BLOCK64 | HANDS_MATH_BF16X3))) return false;          // one summation form
+  if ((d->act & HANDS_SUM_BLOCK64) && (d->act & HANDS_MATH_BF16X3)) return false;
   if (d->Cin % 4 || d->Cout % 4 || d->Kpad % BK || d->Kpad < d->KH * d->KW * d->Cin) return false;
   if (d->Cin != 4 && d->Cin % 16) return false;
   if (d->in_pix_stride < d->Cin || d->out_pix_stride < d->Cout) return false;
@@ -860,8 +902,8 @@ extern "C" int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, 
   }
   // pointwise layers (1x1, no padding; any stride) take the two-source instantiation with the switch
   // point out of reach: no tap state and no bounds checks in the k-loop
-  if (pointwise_route_ok(d)) return (d->Cout <= 64) ? launch<4, 1, 2>(a, s) : launch<2, 2, 2>(a, s);
-  return (d->Cout <= 64) ? launch<4, 1, 0>(a, s) : launch<2, 2, 0>(a, s);
+  if (pointwise_route_ok(d)) return launch_fp32<2>(d, a, s);
+  return launch_fp32<0>(d, a, s);
 }
 
 extern "C" long long hands_conv2d_streamk_workspace_bytes(void) {
@@ -888,7 +930,8 @@ extern "C" int hands_conv2d_nhwc_streamk_f32(const hands_conv_desc* d, const flo
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
-  if (d->act & HANDS_MATH_BF16X3) return hands_conv2d_nhwc_f32(d, in, w_packed, bias, residual, out, stream);
+  if (d->act & (HANDS_MATH_BF16X3 | HANDS_SUM_BLOCK128 | HANDS_SUM_BLOCK64))
+    return hands_conv2d_nhwc_f32(d, in, w_packed, bias, residual, out, stream);
   a.relu = d->act & HANDS_ACT_MASK;
   a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.pre_scale = nullptr; a.pre_shift = nullptr;
   a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
@@ -962,10 +1005,10 @@ int splitk_launch(const hands_conv_desc* d, const float* in, const float* w_pack
   a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (pre) rc = (d->Cout <= 64) ? launch<4, 1, 2, 0, true>(a, s) : launch<2, 2, 2, 0, true>(a, s);
+  if (pre) rc = launch_fp32<2, true>(d, a, s);
   else if (stem) rc = (d->Cout <= 64) ? launch<4, 1, 1>(a, s) : launch<2, 2, 1>(a, s);
-  else if (pointwise_route_ok(d)) rc = (d->Cout <= 64) ? launch<4, 1, 2>(a, s) : launch<2, 2, 2>(a, s);
-  else rc = (d->Cout <= 64) ? launch<4, 1, 0>(a, s) : launch<2, 2, 0>(a, s);
+  else if (pointwise_route_ok(d)) rc = launch_fp32<2>(d, a, s);
+  else rc = launch_fp32<0>(d, a, s);
   if (rc) return rc;
   const long long total = M * (d->Cout / 4);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(hands_grid_1d(total, 256)), dim3(256), 0, s, workspace, S, (int)M,
@@ -987,7 +1030,7 @@ int pre_launch(const hands_conv_desc* d, const float* in, const float* pre_scale
   a.pre_scale = pre_scale; a.pre_shift = pre_shift;
   a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
   hipStream_t s = (hipStream_t)stream;
-  return (d->Cout <= 64) ? launch<4, 1, 2, 0, true>(a, s) : launch<2, 2, 2, 0, true>(a, s);
+  return launch_fp32<2, true>(d, a, s);
 }
 }  // namespace
 

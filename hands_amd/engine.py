@@ -16,6 +16,7 @@ import torch
 from ._lib import ConvDesc, check, ptr
 
 MATH_BF16X3 = 0x100   # HANDS_MATH_BF16X3 (include/hands_hip.h)
+_SUM_BLOCK = {128: 0x200, 64: 0x400}   # HANDS_SUM_BLOCK128 / HANDS_SUM_BLOCK64
 
 
 class ConvEngine:
@@ -44,21 +45,26 @@ class ConvEngine:
         self.fuse_mano = True         # MANOHead.forward of both hands as one launch (hands_mano_heads_f32)
         self.fuse_pre = True          # handoccnet_light's pre-activation units: BatchNorm -> LeakyReLU folded into the operand
                                       # staging of the unit's first (pointwise) convolution (hands_conv2d_nhwc_pre_f32)
-        self.chain_limit = 0          # > 0: blocked fp32 summation.  A direct (non-Winograd) launch whose contraction is at least
-                                      # chain_min_k floats long is cut into S = Kpad / chain_limit K-slices by the deterministic
-                                      # split-K form (partial sums added in slice order), so no fp32 FMA chain is longer than
-                                      # chain_limit floats: fewer roundings per output, at a workspace round trip per such launch.
-                                      # A fixed function of the layer -- batch-size independent.  HandOccNet sets it (DESIGN.md
-                                      # "Conditioning note"); 0 elsewhere
+        self.chain_limit = 0          # > 0: blocked fp32 summation.  In a direct (non-Winograd) launch whose contraction is at least
+                                      # chain_min_k floats long no fp32 FMA chain is longer than chain_limit floats: block sums are
+                                      # added in block order -- inside the launch (chain_in_kernel, below) or by cutting K into
+                                      # S = Kpad / chain_limit slices of the deterministic split-K form (a workspace round trip per
+                                      # such launch).  Fewer roundings per output; a fixed function of the layer -- batch-size
+                                      # independent.  HandOccNet sets it (DESIGN.md "Conditioning note"); 0 elsewhere
         self.chain_min_k = 0          # launches with Kpad below max(chain_min_k, 2 * chain_limit) keep their single chain
         self.chain_skip_tokens = False  # True: token GEMMs (H = W = 1 with >= 4096 rows: the transformer MLPs) keep their single chain
         self.chain_max_pix = 0        # > 0: only launches on maps of at most this many output pixels per image are blocked (the
                                       # workspace round trip is per output element: large maps pay most for the same chain)
+        self.chain_in_kernel = False  # True (chain_limit 128 or 64 only): the blocks are summed INSIDE the launch (desc.act |=
+                                      # HANDS_SUM_BLOCK128 / 64: a second accumulator set, no workspace, no reduce launch) instead
+                                      # of through split-K; launches that are split for another reason block each slice
         self.hook = None              # callable(phase, pc, npix, stream_handle, has_res, kernel): bench.py brackets
                                       # every MFMA launch (conv_igemm and the fused stem) with events; `kernel` is the
                                       # kernel the launch really runs (conv_igemm_f32_kernel / conv_igemm_sk_f32_kernel =
                                       # stream-K / conv_igemm_splitk_f32_kernel = split-K + reduce / stem_pool_*)
         self.last_wino_macs = 0       # executed (not algorithmic) MACs of the Winograd launch the hook is being called for
+        self.last_sum_block = 0       # summation block (floats) of the direct launch the hook is being called for: chain_limit when
+                                      # the launch is blocked (either form), 0 for a single chain
         self._splitk_ws = {}          # (device, stream handle) -> workspace tensor
         self._sk_ws = {}              # (device, stream handle) -> [zeroed stream-K workspace, epoch counter]
         self._capture_ws = {}         # split-K workspaces of launches recorded into the hipGraph being captured (graph memory
@@ -69,7 +75,7 @@ class ConvEngine:
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
         for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "winograd", "winograd4", "fuse_mano", "fuse_pre", "stream_k", "math", "chain_limit",
-                  "chain_min_k", "chain_max_pix", "chain_skip_tokens"):
+                  "chain_min_k", "chain_max_pix", "chain_skip_tokens", "chain_in_kernel"):
             setattr(e, k, getattr(self, k))
         return e
 
@@ -133,6 +139,7 @@ class ConvEngine:
                      (pc.Cout if res_ps is None else res_ps) if res is not None else 0,
                      pc.Kpad, int(relu) | (MATH_BF16X3 if self.math == "bf16x3" else 0))   # relu: bool or a HANDS_ACT_* code
         hook = self.hook
+        self.last_sum_block = 0
         S = L.hands_conv2d_splitk_factor(C.byref(d)) if (splitk and self.use_splitk) else 1
         if splitk_n > 1 and self.use_splitk:
             S = splitk_n
@@ -170,7 +177,13 @@ class ConvEngine:
                 and (not self.chain_max_pix or Ho * Wo <= self.chain_max_pix)
                 and not (self.chain_skip_tokens and H * W == 1 and B >= 4096)):
             # blocked summation (not the Winograd launches above: their chains are Cin long)
-            S = max(S, min(pc.Kpad // self.chain_limit, 32))
+            self.last_sum_block = self.chain_limit
+            if self.chain_in_kernel:
+                if self.chain_limit not in _SUM_BLOCK:
+                    raise ValueError(f"hands_amd: chain_in_kernel takes chain_limit 64 or 128, not {self.chain_limit}")
+                d.act |= _SUM_BLOCK[self.chain_limit]
+            else:
+                S = max(S, min(pc.Kpad // self.chain_limit, 32))
         if pre is not None:
             # pointwise layer behind an eval BatchNorm -> LeakyReLU (pre = (scale, shift) device vectors): the affine +
             # activation is applied to the operand on its way into LDS (hands_conv2d_nhwc_pre_f32)

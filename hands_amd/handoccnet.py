@@ -94,14 +94,16 @@ class HandOccNet(EngineSwitches, nn.Module):
         # direct kernel against ATen's blocked sums.  Two settings shorten them:
         #   * winograd_scope = "all": every 3x3 / stride-1 layer as Winograd F(2x2,3x3), whose chains are Cin long instead of 9 Cin
         #     (and +2-6 % throughput): 0.6 % of inputs above 1e-6 m against 1.1 % with the backbone-only scope of rounds 3-4;
-        #   * engine.chain_limit = 256 (chain_min_k 512): every direct launch with K >= 512 is cut into K / 256 slices by the
-        #     deterministic split-K form, partial sums added in slice order -- no chain longer than 256 floats: 0.3 % [0.10, 0.88]
-        #     above 1e-6 m, maximum 1.07e-6 over 1000 inputs, median HIP-vs-fp64 error 1.49x the reference's own, -4.7 % throughput.
-        # (chain_limit = 128 on every launch: 0 of 1000, median ratio 1.18, -18 %: the opt-in for a caller who wants the margin.)
+        #   * engine.chain_limit = 64, engine.chain_in_kernel: every direct launch with K >= 128 sums blocks of 64 floats (4 k-steps)
+        #     into a second accumulator set inside the kernel (HANDS_SUM_BLOCK64; no workspace, no extra launch): 0 of 1000 inputs
+        #     above 1e-6 m [Wilson 95 %: 0, 0.38 %], median 3.9e-7 / maximum 9.6e-7 m against the reference, and a median HIP-vs-fp64
+        #     error 1.02x the reference's own (maximum 5.9e-7 against the reference's 6.3e-7) -- at -2 % throughput against single chains.
+        # (Blocks of 128: 0 of 1000 as well, ratio 1.17, -0.6 %.  The split-K form of round 5's first half -- chains <= 256 on
+        #  K >= 512 -- gave 0.3 % [0.10, 0.88], ratio 1.49, -1.3 % to -4 %: profiles/r05_hon_parity_ab_1000seeds_d_summary.json.)
         # Call invalidate_packed() after changing the scope.
         self.engine.winograd = True
         self.winograd_scope = "all"        # "all" | "backbone+fit" | "backbone" (trunk + FPN smoothing) | "trunk"
-        self.engine.chain_limit, self.engine.chain_min_k = 256, 512
+        self.engine.chain_limit, self.engine.chain_min_k, self.engine.chain_in_kernel = 64, 0, True
         self.small_map_splitk = True   # call-site constant split-K on maps of <= 8x8 pixels (see _conv_fns)
         self.chunks = 2   # the 2*bz crops run as this many jobs on separate HIP streams (1 = single stream)
         self.async_forward = True   # two forwards in flight: call i runs on pipeline stream i & 1 and is joined at the first

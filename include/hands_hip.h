@@ -78,6 +78,15 @@ typedef struct hands_conv_desc {
  * hands_conv2d_nhwc_f32 and hands_conv1x1_dual_nhwc_f32 (not the RGB0 stem); the split-K / stream-K entries
  * ignore it (fp32). */
 #define HANDS_MATH_BF16X3 0x100
+/* Blocked fp32 summation, OR'ed into desc.act (round 5): the k-ordered FMA chain of every output is cut into blocks of 128 /
+ * 64 floats (8 / 4 k-steps); a block's sum is added to a second accumulator set in block order -- no fp32 accumulation chain
+ * longer than the block, inside the launch (no workspace, no second pass).  Same products, another association: results differ
+ * from the single chain by fp32 rounding and are closer to an fp64 evaluation (and to ATen's blocked CPU sums).  A fixed function
+ * of the layer: batch-size invariant and deterministic.  Honoured by hands_conv2d_nhwc_f32, hands_conv2d_nhwc_pre_f32 and the
+ * split-K entries (each K slice is blocked); ignored by the stem and the dual pointwise entry, the stream-K entry falls back to
+ * the plain launch.  At most one of the two, and not together with HANDS_MATH_BF16X3 (HANDS_EINVAL). */
+#define HANDS_SUM_BLOCK128 0x200
+#define HANDS_SUM_BLOCK64 0x400
 
 int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
                           const float* bias, const float* residual, float* out,

@@ -51,11 +51,16 @@ def test_fp32_conv_kernels_keep_four_workgroups_per_cu(tmp_path):
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     blocks = re.split(r"Function Name: ", p.stderr)[1:]
-    seen = 0
+    seen = blocked = 0
     for b in blocks:
         name = b.split()[0]
-        m = re.search(r"conv_igemm_f32_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)E", name)
+        m = re.search(r"conv_igemm_f32_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELi(\d+)E", name)
         if not m or m.group(4) != "0":     # plain kernel, PREC 0 (exact fp32)
+            continue
+        if m.group(6) != "0":      # blocked summation (HANDS_SUM_BLOCK128 / 64): a second accumulator set, two workgroups per CU
+            vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1)) + int(re.search(r"AGPRs: (\d+)", b).group(1))
+            assert vgprs <= 256 and int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0, (name, vgprs)
+            blocked += 1
             continue
         if m.group(5) == "1":      # PRE (BatchNorm -> LeakyReLU on the operand, handoccnet_light's pre-activation units only):
             continue               # two more staging vectors, 134 VGPRs = 3 workgroups per CU, measured +0.6-1 % over the separate launch
@@ -64,7 +69,7 @@ def test_fp32_conv_kernels_keep_four_workgroups_per_cu(tmp_path):
         lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1))
         assert vgprs + agprs <= 128 and lds <= 40960, (name, vgprs, agprs, lds)
         seen += 1
-    assert seen == 6
+    assert seen == 6 and blocked == 12
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")

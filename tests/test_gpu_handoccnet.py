@@ -138,12 +138,12 @@ def test_handoccnet_forward_vs_golden(golden_dir, hon_gpu, seed):
 
 def test_handoccnet_winograd_scopes_stay_within_fp32_noise(hon_gpu):
     """HandOccNet's default (round 5): Winograd F(2x2,3x3) in EVERY 3x3 / stride-1 layer ("all") and no direct fp32 chain longer
-    than 256 floats (engine.chain_limit = 256 on launches with K >= 512).  "backbone" (trunk + FPN smoothing) was the default of
-    rounds 3-4, engine.winograd = False is the direct kernel everywhere.  This network amplifies any fp32 re-association, so the
-    routes differ by noise of the size each has against the reference (tools/hon_parity_ab.py: medians 5e-7 m): <= 1.5e-6 m
-    between any two of them here, and the launch mix is what the scope says."""
+    than 64 floats (engine.chain_limit = 64 summed inside the launch, on every launch with K >= 128).  "backbone" (trunk + FPN
+    smoothing) was the default of rounds 3-4, engine.winograd = False is the direct kernel everywhere.  This network amplifies any
+    fp32 re-association, so the routes differ by noise of the size each has against the reference (tools/hon_parity_ab.py: medians
+    4-5e-7 m): <= 1.5e-6 m between any two of them here, and the launch mix is what the scope says."""
     assert hon_gpu.engine.winograd is True and hon_gpu.winograd_scope == "all"
-    assert (hon_gpu.engine.chain_limit, hon_gpu.engine.chain_min_k) == (256, 512)
+    assert (hon_gpu.engine.chain_limit, hon_gpu.engine.chain_min_k, hon_gpu.engine.chain_in_kernel) == (64, 0, True)
     inputs, meta_info = synthetic_inputs(2, 0, device=DEV)
     outs, counts, splitk = {}, {}, {}
     try:
@@ -153,10 +153,10 @@ def test_handoccnet_winograd_scopes_stay_within_fp32_noise(hon_gpu):
                 hon_gpu.winograd_scope = scope
                 hon_gpu.invalidate_packed()
             seen = []
-            hon_gpu.conv_hook = lambda phase, pc, npix, st, has_res, kernel: seen.append((kernel, pc.Kpad))
+            hon_gpu.conv_hook = lambda phase, pc, npix, st, has_res, kernel: seen.append((kernel, pc.Kpad, hon_gpu.engine.last_sum_block))
             outs[name] = {k: v.clone() for k, v in hon_gpu(inputs, meta_info).items()}
             hon_gpu.conv_hook = None
-            counts[name] = sum(k == "conv_wino_f32_kernel" for k, _ in seen) // 2
+            counts[name] = sum(k == "conv_wino_f32_kernel" for k, _, _ in seen) // 2
             splitk[name] = seen
     finally:
         hon_gpu.conv_hook = None
@@ -165,8 +165,11 @@ def test_handoccnet_winograd_scopes_stay_within_fp32_noise(hon_gpu):
         hon_gpu.invalidate_packed()
     torch.cuda.synchronize()
     assert counts["direct"] == 0 and counts["backbone"] >= 10 and counts["all"] > counts["backbone"], counts
-    # blocked summation: every direct launch with K >= 512 takes the split-K form, none with K < 512 does because of it
-    assert all(k == "conv_igemm_splitk_f32_kernel" for k, kp in splitk["all"] if kp >= 512 and k.startswith("conv_igemm"))
+    # blocked summation: every direct launch with K >= 128 sums blocks of 64 floats, inside the launch (no launch becomes a
+    # split-K launch because of it: the same kernels as the unblocked "direct" pass chose for themselves)
+    igemm = [(k, kp, blk) for k, kp, blk in splitk["all"] if k.startswith("conv_igemm")]
+    assert igemm and all(blk == (64 if kp >= 128 else 0) for _, kp, blk in igemm), igemm
+    assert sum(k == "conv_igemm_splitk_f32_kernel" for k, _, _ in igemm) <= sum(k == "conv_igemm_splitk_f32_kernel" for k, _, _ in splitk["direct"])
     for a_, b_ in (("backbone", "all"), ("backbone", "direct"), ("all", "direct")):
         for hn in "rl":
             assert (outs[a_][f"mano.vertices.{hn}"] - outs[b_][f"mano.vertices.{hn}"]).abs().max().item() < 1.5e-6, (a_, b_)

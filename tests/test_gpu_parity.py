@@ -980,6 +980,75 @@ def test_splitk_n_is_deterministic_and_right(case):
     assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+SUM_BLOCK_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, act, residual, pre, splitk_n
+    (8, 512, 7, 7, 512, 3, 1, 1, 1, False, False, 0),      # K = 4608, the 128 x 128 tile, general route (36 / 72 blocks)
+    (8, 256, 8, 8, 64, 3, 2, 1, 3, False, False, 0),       # the 256 x 64 tile, stride 2, K = 2304
+    (300, 2048, 1, 1, 512, 1, 1, 0, 0, True, False, 0),    # pointwise route + residual, ragged M
+    (16, 1024, 4, 4, 112, 1, 1, 0, 3, False, True, 0),     # BatchNorm -> LeakyReLU folded into the operand (the pre entry), N tail
+    (64, 2304, 1, 1, 2048, 1, 1, 0, 1, False, False, 3),   # a launch that is split for another reason: every slice is blocked
+    (5, 80, 9, 9, 40, 3, 1, 1, 2, False, False, 0),        # K = 720: a partial last block
+    (5, 16, 9, 9, 40, 3, 1, 1, 1, False, False, 0),        # K = 144: below two blocks, the single chain stays
+]
+
+
+@pytest.mark.parametrize("case", SUM_BLOCK_CASES)
+@pytest.mark.parametrize("limit", [64, 128])
+def test_in_kernel_blocked_summation(case, limit):
+    """engine.chain_in_kernel (desc.act | HANDS_SUM_BLOCK128 / 64): the k-ordered chain of every output is cut into blocks of
+    `limit` floats inside the launch.  Right against an fp64 convolution, no farther from it than the single chain on average,
+    bit-reproducible, independent of the batch size, one launch (no split-K workspace pass), and -- where the split-K form of
+    the same blocking exists (K / limit <= 32 equal slices) -- within rounding of it."""
+    B, Cin, H, W, Cout, k, stride, pad, act, use_res, use_pre, S = case
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(sum(case) + limit)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    pc = pack_conv(w, torch.randn(Cout, generator=g), stride, pad, DEV)
+    x = torch.randn(B, H, W, Cin, generator=g).to(DEV)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Ho, Wo, pc.Cout, generator=g).to(DEV) if use_res else None
+    pre = (torch.rand(Cin, generator=g).to(DEV) + 0.5, torch.randn(Cin, generator=g).to(DEV) * 0.1) if use_pre else None
+    kernels = []
+
+    def run(blocked, xs=x, rs=res, in_kernel=True):
+        eng = ConvEngine()
+        eng.winograd = False
+        if blocked:
+            eng.chain_limit, eng.chain_in_kernel = limit, in_kernel
+        eng.hook = lambda phase, pc_, npix, st, has_res, kernel: kernels.append(kernel) if phase == "begin" else None
+        out = torch.full((xs.shape[0], Ho, Wo, pc.Cout), float("nan"), device=DEV)
+        eng.conv(L, pc, xs, xs.shape[0], H, W, out, act, _stream(), res=rs, splitk_n=S, pre=pre)
+        torch.cuda.synchronize()
+        return out
+
+    plain, blocked = run(False), run(True)
+    applies = pc.Kpad >= 2 * limit
+    assert kernels[-1] == ("conv_igemm_splitk_f32_kernel" if S > 1 else "conv_igemm_f32_kernel")     # no extra split
+    assert torch.equal(run(True), blocked)
+    if not applies:
+        assert torch.equal(blocked, plain)
+    nb = max(1, B // 3)
+    assert torch.equal(run(True, x[:nb].contiguous(), res[:nb].contiguous() if use_res else None), blocked[:nb])
+    xin = x.permute(0, 3, 1, 2).double().cpu()
+    if use_pre:
+        xin = F.leaky_relu(xin * pre[0].double().cpu().view(1, -1, 1, 1) + pre[1].double().cpu().view(1, -1, 1, 1), 0.01)
+    ref = F.conv2d(xin, w.double(), pc.bias[:Cout].double().cpu(), stride=stride, padding=pad)
+    if res is not None:
+        ref = ref + res.permute(0, 3, 1, 2)[:, :Cout].double().cpu()
+    ref = {0: ref, 1: F.relu(ref), 2: F.gelu(ref), 3: F.leaky_relu(ref, 0.01)}[act]
+    err = lambda o: (o.permute(0, 3, 1, 2)[:, :Cout].double().cpu() - ref).abs()
+    eb, ep = err(blocked), err(plain)
+    assert eb.max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    if applies:
+        assert eb.mean().item() <= ep.mean().item() * 1.02, (eb.mean().item(), ep.mean().item())
+        if pc.Kpad >= 1024:       # long chains: blocking visibly helps
+            assert eb.mean().item() < 0.9 * ep.mean().item(), (eb.mean().item(), ep.mean().item())
+    if applies and S <= 1 and pc.Kpad % limit == 0 and pc.Kpad // limit <= 32:
+        via_splitk = run(True, in_kernel=False)
+        assert kernels[-1] == "conv_igemm_splitk_f32_kernel"
+        assert (via_splitk - blocked).abs().max().item() <= 4e-6 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("name", SWITCH_CASES)
 def test_switch_configurations_vs_reference_fixtures(golden_dir, name):
     """Non-default HandsLight switches through the HIP path against what the REFERENCE produced for them

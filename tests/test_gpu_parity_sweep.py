@@ -63,8 +63,8 @@ def test_handoccnet_default_scope_multi_seed_parity(golden_dir):
     model = hands_amd.apply_recipe(hands_amd.HandOccNet())
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(DEV).eval()
-    assert model.engine.winograd and model.winograd_scope == "all" and model.engine.chain_limit == 256, \
-        "shipped default (round 5): Winograd in every 3x3 / stride-1 layer, direct chains <= 256 floats"
+    assert model.engine.winograd and model.winograd_scope == "all" and model.engine.chain_limit == 64 and model.engine.chain_in_kernel, \
+        "shipped default (round 5): Winograd in every 3x3 / stride-1 layer, direct chains <= 64 floats (summed inside the launch)"
     rows, worst = _sweep(model, sd, HO.handoccnet_forward, "handoccnet_light")
     assert len(rows) >= 8
     assert worst["max_vertex_err_m"] <= BAR_M and max(r["mpjpe_mm"] for r in rows) <= BAR_MPJPE_MM, worst
@@ -80,14 +80,16 @@ def test_handoccnet_default_scope_multi_seed_parity(golden_dir):
 
 
 def test_handoccnet_error_distribution_guard():
-    """48 more input seeds (200-247) through the shipped default route (Winograd everywhere + chains <= 256 floats).  Round 5's
-    1000-seed A/B (tools/hon_parity_ab.py, profiles/r05_hon_parity_ab_*.json): 0.3 % [0.10, 0.88] of inputs above 1e-6 m, median
-    5.0e-7, p90 6.9e-7, maximum 1.07e-6; these 48 seeds measured 0 above 1e-6 (max 8.9e-7) against the live oracle.  Guard: at most
-    ONE of the 48 above 1e-6 m and none above 1.2e-6 m (round 4 tolerated three and 1.6e-6), median <= 6e-7, p90 <= 8e-7.
+    """48 more input seeds (200-247) through the shipped default route (Winograd everywhere + direct chains <= 64 floats, summed
+    inside the launch).  Round 5's 1000-seed A/B (tools/hon_parity_ab.py, profiles/r05_hon_parity_ab_1000seeds_d_summary.json): 0
+    of 1000 inputs above 1e-6 m [Wilson 95 %: 0, 0.38 %], median 3.9e-7, p90 5.6e-7, maximum 9.6e-7.  Guard (the oracle here is
+    LIVE, and ATen's fp32 sums differ by 3-6e-7 m between host CPUs, so one input may land anywhere in that tail): at most ONE of
+    the 48 above 1e-6 m and none above 1.1e-6 m (round 4 tolerated three and 1.6e-6), median <= 5.5e-7, p90 <= 7.5e-7 (measured on
+    two boxes: 0 above 1e-6, median 4.3e-7, p90 6.6e-7, max 7.8e-7).
 
-    And the other half of the claim: the HIP path is about as accurate as the reference itself.  Against an fp64 evaluation of
-    the same network on the first 12 of the seeds, the median of err(HIP, fp64) / err(fp32 oracle, fp64) is <= 1.75 (measured 1.49
-    over 1000 seeds; the fp32 oracle -- the reference's arithmetic -- is a median 2.9e-7 m from fp64 itself)."""
+    And the other half of the claim: the HIP path is as accurate as the reference itself.  Against an fp64 evaluation of the same
+    network on the first 12 of the seeds, the median of err(HIP, fp64) / err(fp32 oracle, fp64) is <= 1.4 (measured 1.02 over
+    1000 seeds; the fp32 oracle -- the reference's arithmetic -- is a median 2.9e-7 m from fp64 itself)."""
     model = hands_amd.apply_recipe(hands_amd.HandOccNet())
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
@@ -107,5 +109,5 @@ def test_handoccnet_error_distribution_guard():
     e = np.sort(np.array(errs))
     print(f"handoccnet_light, 48 seeds: median {np.median(e):.3e}, p90 {np.percentile(e, 90):.3e}, max {e[-1]:.3e}, above 1e-6: {(e > 1e-6).sum()}; "
           f"err(HIP, fp64) / err(oracle fp32, fp64) over 12 seeds: median {np.median(ratios):.2f}, max {max(ratios):.2f}")
-    assert np.median(e) <= 6e-7 and np.percentile(e, 90) <= 8e-7 and (e > 1e-6).sum() <= 1 and e[-1] <= 1.2e-6, e[-6:]
-    assert np.median(ratios) <= 1.75, ratios
+    assert np.median(e) <= 5.5e-7 and np.percentile(e, 90) <= 7.5e-7 and (e > 1e-6).sum() <= 1 and e[-1] <= 1.1e-6, e[-6:]
+    assert np.median(ratios) <= 1.4, ratios

@@ -18,18 +18,18 @@ from hon_parity_ab import parse_arm
 from oracle import handoccnet_oracle as HO
 
 torch.set_num_threads(min(8, os.cpu_count() or 1))
-arms = (sys.argv[1] if len(sys.argv) > 1 else "backbone,all,all+c256,all+c128k512").split(",")
+arms = (sys.argv[1] if len(sys.argv) > 1 else "backbone,all,all+c256k512,all+c128i,all+c64i").split(",")
 ar, al = hands_amd.synthetic_mano_asset(True), hands_amd.synthetic_mano_asset(False)
 base = hands_amd.apply_recipe(hands_amd.HandOccNet())
 sd = {k: v.clone() for k, v in base.state_dict().items()}
 models = {}
 for name in arms:
-    scope, limit, min_k, max_pix, skip_tok = parse_arm(name)
+    scope, limit, min_k, max_pix, skip_tok, in_kernel = parse_arm(name)
     m = hands_amd.apply_recipe(hands_amd.HandOccNet()).to("cuda").eval()
     m.engine.winograd = scope != "direct"
     m.winograd_scope = scope if scope != "direct" else "backbone"
     m.engine.chain_limit, m.engine.chain_min_k, m.engine.chain_max_pix = limit, min_k, max_pix
-    m.engine.chain_skip_tokens = skip_tok
+    m.engine.chain_skip_tokens, m.engine.chain_in_kernel = skip_tok, in_kernel
     m.invalidate_packed()
     m.async_forward = False
     models[name] = m

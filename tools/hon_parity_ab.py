@@ -9,7 +9,7 @@ processes (8 threads each) created before the parent touches the GPU.
 
 usage: python tools/hon_parity_ab.py [--seeds N] [--first S] [--arms a,b,...] [--workers W] [--out gpurun_out/hon_ab.json]
        [--speed]   (hands/s of every arm at bz = 32 and 256, shipped pipelined mode)
-arm syntax: <scope>[+c<chain_limit>[k<chain_min_k>][p<chain_max_pix>][t = token GEMMs unblocked]], scope in direct | trunk | backbone | backbone+fit | all
+arm syntax: <scope>[+c<chain_limit>[k<chain_min_k>][p<chain_max_pix>][t = token GEMMs unblocked][i = blocks summed inside the launch]], scope in direct | trunk | backbone | backbone+fit | all
 """
 import argparse
 import json
@@ -62,20 +62,20 @@ def wilson(k, n, z=1.96):
 def parse_arm(name):
     scope, _, rest = name.partition("+c")
     limit = min_k = max_pix = 0
-    skip_tok = rest.endswith("t")
-    rest = rest.rstrip("t")
+    skip_tok, in_kernel = "t" in rest, "i" in rest
+    rest = rest.rstrip("ti")
     if rest:
         rest, _, mp = rest.partition("p")
         lim, _, mk = rest.partition("k")
         limit, min_k, max_pix = int(lim), int(mk or 0), int(mp or 0)
-    return scope, limit, min_k, max_pix, skip_tok
+    return scope, limit, min_k, max_pix, skip_tok, in_kernel
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=1000)
     ap.add_argument("--first", type=int, default=1000)
-    ap.add_argument("--arms", default="backbone,backbone+c512,backbone+c256,all,all+c512,all+c256,all+c128")
+    ap.add_argument("--arms", default="backbone,all,all+c256k512,all+c128i,all+c64i")
     ap.add_argument("--workers", type=int, default=2)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "hon_ab.json"))
     ap.add_argument("--speed", action="store_true")
@@ -107,12 +107,12 @@ def main():
     from hands_amd.weights import synthetic_inputs
     models = {}
     for name in arms:
-        scope, limit, min_k, max_pix, skip_tok = parse_arm(name)
+        scope, limit, min_k, max_pix, skip_tok, in_kernel = parse_arm(name)
         m = hands_amd.apply_recipe(hands_amd.HandOccNet()).to("cuda").eval()
         m.engine.winograd = scope != "direct"
         m.winograd_scope = scope if scope != "direct" else "backbone"
         m.engine.chain_limit, m.engine.chain_min_k, m.engine.chain_max_pix = limit, min_k, max_pix
-        m.engine.chain_skip_tokens = skip_tok
+        m.engine.chain_skip_tokens, m.engine.chain_in_kernel = skip_tok, in_kernel
         m.invalidate_packed()
         m.async_forward = False
         models[name] = m
