@@ -779,7 +779,31 @@ def parity_sweep(ctx, workload, model, sd_cpu):
 def stored_exceed_rate(workload, model):
     """handoccnet_light: the share of random inputs whose max vertex error against the reference exceeds 1e-6 m, from the committed
     1000-seed A/B of the setting this model runs (profiles/r05_hon_parity_ab_1000seeds*_summary.json, tools/hon_parity_ab.py) -- a
-    STORED figure (the run takes 2 minutes of CPU forwards), named as such; absent for any other setting."""
+    STORED figure (the run takes 2 minutes of CPU forwards), named as such; absent for any other setting.  hands_light: the same from
+    profiles/r05_hl_parity_ab_1000seeds_summary.json (tools/hl_parity_ab.py), arm = the 3x3 route the model runs."""
+    def pick(files, arm):
+        for fn in files:
+            try:
+                d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                a = d["arms"].get(arm)
+                if a:
+                    return {"exceed_rate": round(a["exceed_rate"], 4), "exceed_wilson95": [round(v, 4) for v in a["wilson95"]],
+                            "exceed_n": d["n"], "median_err_ratio_vs_fp64": round(a["median_ratio_hip64_over_ref64"], 2),
+                            "exceed_source": f"stored: profiles/{fn} arm {arm}"}
+            except (OSError, ValueError, KeyError):
+                continue
+        return {}
+
+    if workload == "hands_light" and hasattr(model, "winograd4_stages") and getattr(model.engine, "math", "fp32") == "fp32":
+        if not model.engine.winograd:
+            arm = "direct"
+        elif model.engine.winograd4 and tuple(model.winograd4_stages) == (1, 2, 3, 4):
+            arm = "f4x4"
+        elif not (model.engine.winograd4 and model.winograd4_stages):
+            arm = "f2x2"
+        else:
+            return {}
+        return pick(("r05_hl_parity_ab_1000seeds_summary.json",), arm)
     if workload != "handoccnet_light" or not hasattr(model, "winograd_scope"):
         return {}
     e = model.engine
@@ -790,18 +814,8 @@ def stored_exceed_rate(workload, model):
             arm += f"k{e.chain_min_k}"
         if getattr(e, "chain_in_kernel", False):
             arm += "i"
-    for fn in ("r05_hon_parity_ab_1000seeds_d_summary.json", "r05_hon_parity_ab_1000seeds_summary.json",
-               "r05_hon_parity_ab_1000seeds_b_summary.json"):
-        try:
-            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
-            a = d["arms"].get(arm)
-            if a:
-                return {"exceed_rate": round(a["exceed_rate"], 4), "exceed_wilson95": [round(v, 4) for v in a["wilson95"]],
-                        "exceed_n": d["n"], "median_err_ratio_vs_fp64": round(a["median_ratio_hip64_over_ref64"], 2),
-                        "exceed_source": f"stored: profiles/{fn} arm {arm}"}
-        except (OSError, ValueError, KeyError):
-            continue
-    return {}
+    return pick(("r05_hon_parity_ab_1000seeds_d_summary.json", "r05_hon_parity_ab_1000seeds_summary.json",
+                 "r05_hon_parity_ab_1000seeds_b_summary.json"), arm)
 
 
 def cpu_baseline_hands_light(ctx, model, sd_cpu):

@@ -198,7 +198,9 @@ class ConvEngine:
                 hook("end", pc, B * Ho * Wo, stream, res is not None, kname)
             return Ho, Wo
         use_sk = S <= 1 and self.math == "fp32" and ((not self.overlap) if self.stream_k == "auto" else self.stream_k) and \
+            not (d.act & (_SUM_BLOCK[64] | _SUM_BLOCK[128])) and \
             L.hands_conv2d_streamk_grid(C.byref(d)) > 0 and not self._capturing(L, stream)
+        # (a blocked launch keeps the plain kernel: stream-K continues ONE chain across workgroups)
         # (not under hipGraph capture: the zero-filled workspace of a new stream cannot be set up inside one)
         kname = "conv_igemm_splitk_f32_kernel" if S > 1 else ("conv_igemm_sk_f32_kernel" if use_sk else "conv_igemm_f32_kernel")
         if hook is not None:
