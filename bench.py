@@ -804,6 +804,8 @@ def stored_exceed_rate(workload, model):
         else:
             return {}
         return pick(("r05_hl_parity_ab_1000seeds_summary.json",), arm)
+    if workload == "hamer_light" and getattr(model.engine, "math", "fp32") == "fp32":
+        return pick(("r05_hm_parity_ab_400seeds_summary.json",), "default")
     if workload != "handoccnet_light" or not hasattr(model, "winograd_scope"):
         return {}
     e = model.engine
@@ -814,6 +816,8 @@ def stored_exceed_rate(workload, model):
             arm += f"k{e.chain_min_k}"
         if getattr(e, "chain_in_kernel", False):
             arm += "i"
+    if not getattr(model, "small_map_splitk", False):       # the runs before `_e_` had the small-map split-K rules on
+        return pick(("r05_hon_parity_ab_1000seeds_e_summary.json",), arm)
     return pick(("r05_hon_parity_ab_1000seeds_d_summary.json", "r05_hon_parity_ab_1000seeds_summary.json",
                  "r05_hon_parity_ab_1000seeds_b_summary.json"), arm)
 

@@ -42,13 +42,13 @@ def _conv_fns(L, stream, new, engine, small_map_splitk=True):
         Ho = (H + 2 * pc.pad - pc.KH) // pc.stride + 1
         Wo = (W + 2 * pc.pad - pc.KW) // pc.stride + 1
         out = out if out is not None else new(B, Ho, Wo, pc.Cout)
-        if small_map_splitk and H * W > 1 and Ho * Wo <= 64 and "splitk" not in kw:
+        if small_map_splitk in (True, "deep") and H * W > 1 and Ho * Wo <= 64 and "splitk" not in kw:
             # 8x8 ... 2x2 maps (layer4, the deep hourglass / encoder levels): a handful of output tiles
             # walking K = 1152-4608 serially.  The slice count depends on the map size and K only, never
             # on the batch, so every output bit stays independent of the batch size.
             S = 4 if Ho * Wo > 16 else 8
             kw["splitk_n"] = max(1, min(S, pc.Kpad // 128))
-        elif (small_map_splitk and H * W > 1 and Ho * Wo <= 256 and pc.Cout <= 128 and pc.Kpad >= 1024
+        elif (small_map_splitk in (True, "16x16") and H * W > 1 and Ho * Wo <= 256 and pc.Cout <= 128 and pc.Kpad >= 1024
               and "splitk" not in kw):
             kw["splitk_n"] = 2          # 16x16 maps, one n-tile: 2 output tiles per crop
         engine.conv(L, pc, x, B, H, W, out, act, stream, res=res, **kw)
@@ -104,7 +104,11 @@ class HandOccNet(EngineSwitches, nn.Module):
         self.engine.winograd = True
         self.winograd_scope = "all"        # "all" | "backbone+fit" | "backbone" (trunk + FPN smoothing) | "trunk"
         self.engine.chain_limit, self.engine.chain_min_k, self.engine.chain_in_kernel = 64, 0, True
-        self.small_map_splitk = True   # call-site constant split-K on maps of <= 8x8 pixels (see _conv_fns)
+        self.small_map_splitk = False  # True / "deep" / "16x16": call-site constant split-K on maps of <= 8x8 pixels and on the
+                                       # one-tile 16x16 layers (see _conv_fns).  Off since round 5: with three forwards in flight the
+                                       # chip is filled by other forwards, and the reduce launches cost more than the slices gain
+                                       # (tools/ab_small_map_splitk.py: +2.3 % at 32 samples, +2.9 % at 256); True shortens ONE
+                                       # synchronous forward at 2 samples by 6 % (6.5 against 6.9 ms)
         self.chunks = 2   # the 2*bz crops run as this many jobs on separate HIP streams (1 = single stream)
         self.async_forward = True   # two forwards in flight: call i runs on pipeline stream i & 1 and is joined at the first
                                     # use of its result (stream_xdict), so the launches of consecutive calls fill each other's

@@ -71,7 +71,7 @@ def decoder_forward(context, sd, p="mano_head", depth=DEC_DEPTH):
     {PreNorm self-attn, PreNorm cross-attn to the 192x1280 context, PreNorm FF(GELU)}."""
     B = context.shape[0]
     t = p + ".transformer"
-    token = torch.zeros(B, 1, 1)
+    token = torch.zeros(B, 1, 1, dtype=context.dtype)          # (fp64 evaluations of the oracle: tools/hm_parity_ab.py)
     x = _lin(token, sd, t + ".to_token_embedding") + sd[t + ".pos_embedding"][:, :1]
     scale = DEC_DHEAD ** -0.5
     split = lambda z: z.view(B, -1, DEC_HEADS, DEC_DHEAD).transpose(1, 2)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""hands_light (the headline configuration): many-seed parity of the HIP forward per 3x3 route, with statistics.
+"""hands_light (the headline configuration; --workload hamer_light: config 3 at bz = 1, one arm): many-seed parity of the HIP forward
+per 3x3 route, with statistics.
 
 Per seed (bz = 2 -> 4 hands) and per arm: max vertex error against the fp32 oracle (= the reference's arithmetic) AND against an
 fp64 evaluation of the same network, so "the HIP path is as accurate as the reference" is a number: the median of
@@ -25,11 +26,12 @@ os.environ.setdefault("HANDS_SYNTHETIC_MANO", "1")
 _W = {}
 
 
-def _init():
+def _init(workload="hands_light"):
     import torch
     import hands_amd
     torch.set_num_threads(min(8, os.cpu_count() or 1))
-    m = hands_amd.apply_recipe(hands_amd.HandsLight())
+    _W["workload"] = workload
+    m = hands_amd.apply_recipe(hands_amd.HandsLight() if workload == "hands_light" else hands_amd.HAMER())
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     _W["sd"] = sd
     _W["sd64"] = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
@@ -39,11 +41,16 @@ def _init():
 def _refs(seed):
     import torch
     from hands_amd.weights import synthetic_inputs
-    from oracle import hands_oracle as O
+    if _W["workload"] == "hands_light":
+        from oracle import hands_oracle as O
+        fwd, bz = O.hands_light_forward, 2
+    else:
+        from oracle import hamer_oracle as HM
+        fwd, bz = HM.hamer_forward, 1
     c64 = lambda d: {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}
-    ci, cm = synthetic_inputs(2, seed)
-    r32 = O.hands_light_forward(_W["sd"], _W["ar"], _W["al"], ci, cm)
-    r64 = O.hands_light_forward(_W["sd64"], _W["ar"], _W["al"], c64(ci), c64(cm))
+    ci, cm = synthetic_inputs(bz, seed)
+    r32 = fwd(_W["sd"], _W["ar"], _W["al"], ci, cm)
+    r64 = fwd(_W["sd64"], _W["ar"], _W["al"], c64(ci), c64(cm))
     v32 = torch.stack([r32[f"mano.vertices.{h}"] for h in "rl"]).numpy()
     v64 = torch.stack([r64[f"mano.vertices.{h}"] for h in "rl"]).numpy()
     return v32, v64
@@ -52,6 +59,7 @@ def _refs(seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--precompute", action="store_true")
+    ap.add_argument("--workload", default="hands_light", choices=("hands_light", "hamer_light"))
     ap.add_argument("--seeds", type=int, default=1000)
     ap.add_argument("--first", type=int, default=1000)
     ap.add_argument("--refs", default=None)
@@ -61,9 +69,10 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "hl_ab.json"))
     a = ap.parse_args()
     import numpy as np
-    _init()
+    _init(a.workload)
+    hamer = a.workload == "hamer_light"
     if a.precompute:
-        out = os.path.join(ROOT, "build_ab", f"hl_refs_{a.first}_{a.seeds}.npz")
+        out = os.path.join(ROOT, "build_ab", f"{'hm' if hamer else 'hl'}_refs_{a.first}_{a.seeds}.npz")
         os.makedirs(os.path.dirname(out), exist_ok=True)
         v32s, v64s = [], []
         t0 = time.time()
@@ -85,10 +94,13 @@ def main():
         v32, v64 = _refs(s)
         print(f"refs check seed {s}: stored vs live fp32 {np.abs(z['v32'][s - first] - v32).max():.3e}, "
               f"fp64 {np.abs(z['v64'][s - first] - v64).max():.3e}", flush=True)
-    arms = a.arms.split(",")
+    arms = ["default"] if hamer else a.arms.split(",")
     models = {}
     for name in arms:
         route, _, rest = name.partition("+c")          # "+c<limit>[k<min_k>]": blocked summation inside the launch
+        if hamer:
+            models[name] = hands_amd.apply_recipe(hands_amd.HAMER()).to("cuda").eval()
+            continue
         m = hands_amd.apply_recipe(hands_amd.HandsLight())
         if route != "f4x4":
             m.winograd4_stages = ()
@@ -105,7 +117,7 @@ def main():
     t0 = time.time()
     for i, seed in enumerate(seeds):
         v32, v64 = z["v32"][seed - first], z["v64"][seed - first]
-        ci, cm = synthetic_inputs(2, seed)
+        ci, cm = synthetic_inputs(1 if hamer else 2, seed)
         gi, gm = {k: v.to("cuda") for k, v in ci.items()}, {k: v.to("cuda") for k, v in cm.items()}
         res["seeds"].append(seed)
         res["ref32_vs_64"].append(float(np.abs(v32.astype(np.float64) - v64).max()))
@@ -133,7 +145,7 @@ def main():
         print(f"{name:8s} vs ref32: > 1e-6 {k:3d}/{n} = {100 * k / n:.2f} % [{100 * lo:.2f}, {100 * hi:.2f}]  median {np.median(e):.3e} "
               f"p90 {np.percentile(e, 90):.3e} p99 {np.percentile(e, 99):.3e} max {e.max():.3e} | vs fp64: median {np.median(e64):.3e} "
               f"p99 {np.percentile(e64, 99):.3e} max {e64.max():.3e}, median err(HIP,64) / err(ref32,64) = {np.median(ratio):.2f}")
-    if a.speed:        # arms alternate (clocks drift over a call): four rounds of six forwards each, best and median per arm
+    if a.speed and not hamer:        # arms alternate (clocks drift over a call): four rounds of six forwards each, best and median per arm
         gi, gm = synthetic_inputs(256, 0, device="cuda")
         times = {name: [] for name in models}
         for name, m in models.items():
