@@ -499,8 +499,9 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         model.engine.winograd = bool(winograd)
     if winograd_scope is not None and hasattr(model, "winograd_scope"):    # HandOccNet: default "all" + chains <= 128 floats
         model.winograd_scope = winograd_scope
-        if winograd_scope == "backbone":           # the comparison line: rounds 3-4's default, single fp32 chains
+        if winograd_scope == "backbone":           # the comparison line: rounds 3-4's default, single fp32 chains, small-map split-K
             model.engine.chain_limit = 0
+            model.small_map_splitk = True
         model.invalidate_packed()
     if os.environ.get("HANDS_WINO4_STAGES") is not None and hasattr(model, "winograd4_stages"):    # developer A/B switch: "", "4", "1234"
         model.winograd4_stages = tuple(int(c) for c in os.environ["HANDS_WINO4_STAGES"])
