@@ -109,7 +109,8 @@ class HandOccNet(EngineSwitches, nn.Module):
                                        # chip is filled by other forwards, and the reduce launches cost more than the slices gain
                                        # (tools/ab_small_map_splitk.py: +2.3 % at 32 samples, +2.9 % at 256); True shortens ONE
                                        # synchronous forward at 2 samples by 6 % (6.5 against 6.9 ms)
-        self.chunks = 2   # the 2*bz crops run as this many jobs on separate HIP streams (1 = single stream)
+        self.chunks = 2   # a forward that runs ALONE (async_forward off) splits its 2*bz crops into this many jobs on separate HIP
+                          # streams (1 = single stream); pipelined forwards run one job each
         self.async_forward = True   # two forwards in flight: call i runs on pipeline stream i & 1 and is joined at the first
                                     # use of its result (stream_xdict), so the launches of consecutive calls fill each other's
                                     # tails -- at 32 samples per GPU a launch is 1-4 tiles per CU, all in phase when alone
@@ -299,7 +300,7 @@ class HandOccNet(EngineSwitches, nn.Module):
                 for evd in self._pipe_done.values():     # a synchronous call is ordered after every forward still in flight
                     main.wait_event(evd)
         with torch.cuda.stream(st):
-            output = self._forward_body(L, P, dev, x4, center, corner, K, bz)
+            output = self._forward_body(L, P, dev, x4, center, corner, K, bz, pipelined)
         if not pipelined:
             return output
         ready = torch.cuda.Event()
@@ -307,7 +308,7 @@ class HandOccNet(EngineSwitches, nn.Module):
         self._pipe_done[par] = ready
         return stream_xdict(output, ready, dev)
 
-    def _forward_body(self, L, P, dev, x4, center, corner, K, bz):
+    def _forward_body(self, L, P, dev, x4, center, corner, K, bz, pipelined=False):
         """Everything after the input resize (model.py:72-129), enqueued on torch's CURRENT stream."""
         B2, S = 2 * bz, 256
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -475,7 +476,10 @@ class HandOccNet(EngineSwitches, nn.Module):
         main = torch.cuda.current_stream(dev)
         # measured (bz=32 -> 64 crops): 2 chunks without split-K lose 8 % (smaller launches), with
         # latency_mode they gain 4 %; at 512 crops they gain 3 %
-        nch = self.chunks if (dbg is None and self.engine.overlap and (B2 >= 128 or self.engine.latency_mode)) else 1
+        # round 5, several forwards in flight (tools/ab_pipeline_depth.py): the other forwards fill the chip and one job per
+        # forward is 0.6-1.4 % faster at 512 crops -- the crop jobs are for a forward that runs alone
+        nch = self.chunks if (dbg is None and self.engine.overlap and not pipelined
+                              and (B2 >= 128 or self.engine.latency_mode)) else 1
         nch = max(1, min(nch, B2))
         if nch == 1:
             pred = pipeline(x4, center, corner, B2, stream)
