@@ -1049,6 +1049,31 @@ def test_in_kernel_blocked_summation(case, limit):
         assert (via_splitk - blocked).abs().max().item() <= 4e-6 * max(1.0, ref.abs().max().item())
 
 
+def test_summation_flags_are_exclusive_and_chain_in_kernel_rejects_other_lengths():
+    """desc.act carries at most ONE summation form: both block flags, or a block flag with HANDS_MATH_BF16X3, are an invalid
+    descriptor (HANDS_EINVAL = 10001, nothing launched); engine.chain_in_kernel with a block length the kernel has no
+    instantiation for raises before anything is launched."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    pc = pack_conv(torch.randn(128, 256, 1, 1, generator=g) / 16, torch.randn(128, generator=g), 1, 0, DEV)
+    x = torch.randn(4, 8, 8, 256, generator=g).to(DEV)
+    out = torch.full((4, 8, 8, 128), float("nan"), device=DEV)
+    for flags in (0x200 | 0x400, 0x200 | 0x100, 0x400 | 0x100, 0x800):
+        d = _lib.ConvDesc(4, 8, 8, 256, 8, 8, 128, 1, 1, 1, 0, 256, 128, 0, pc.Kpad, 1 | flags)
+        assert L.hands_conv2d_nhwc_f32(C.byref(d), ptr(x), ptr(pc.w), ptr(pc.bias), None, ptr(out), _stream()) == 10001, hex(flags)
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all()
+    eng = ConvEngine()
+    eng.chain_limit, eng.chain_in_kernel = 96, True
+    with pytest.raises(ValueError, match="chain_in_kernel"):
+        eng.conv(L, pc, x, 4, 8, 8, out, 1, _stream())
+    eng.chain_in_kernel = False                    # the split-K form takes any block length
+    eng.chain_limit = 128
+    eng.conv(L, pc, x, 4, 8, 8, out, 1, _stream())
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and eng.last_sum_block == 128
+
+
 @pytest.mark.parametrize("name", SWITCH_CASES)
 def test_switch_configurations_vs_reference_fixtures(golden_dir, name):
     """Non-default HandsLight switches through the HIP path against what the REFERENCE produced for them
