@@ -45,18 +45,26 @@ for v in range(nvar):
             m(gi, gm)
         torch.cuda.synchronize()
     sets.append(m._ws)
+# (a') new buffers but the FIRST set's streams and events: is it the memory or the streams (HIP maps streams onto 4 hardware queues)?
+held.append(torch.empty(99 << 20, dtype=torch.uint8, device="cuda"))
+m._ws = {k: v for k, v in sets[0].items() if not torch.is_tensor(v)}
+for _ in range(2):
+    m(gi, gm)
+torch.cuda.synchronize()
+sets.append(m._ws)
+nvar_a = len(sets)
 addr = lambda ws: sorted((k, v.data_ptr()) for k, v in ws.items() if torch.is_tensor(v) and v.numel() > (1 << 24))
-ta = {v: [] for v in range(nvar)}
+ta = {v: [] for v in range(nvar_a)}
 for r in range(rounds):
-    for v in range(nvar):
+    for v in range(nvar_a):
         m._ws = sets[v]
         ta[v].append(timed(m))
 base = float(np.median(ta[0]))
 print("(a) one instance, workspace placements:")
-for v in range(nvar):
+for v in range(nvar_a):
     md = float(np.median(ta[v]))
     big = addr(sets[v])
-    print(f"  placement {v}: {2 * bz / md:8.1f} hands/s ({100 * (base / md - 1):+5.2f} %)  best {2 * bz / min(ta[v]):8.1f}; "
+    print(f"  placement {v}{' (new buffers, streams of placement 0)' if v == nvar_a - 1 else ''}: {2 * bz / md:8.1f} hands/s ({100 * (base / md - 1):+5.2f} %)  best {2 * bz / min(ta[v]):8.1f}; "
           f"{len(big)} buffers > 64 MB, first at {big[0][1]:#x} ({big[0][1] % (1 << 21):#x} mod 2 MB)")
 m._ws = sets[0]
 # (b) fresh instances
