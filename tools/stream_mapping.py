@@ -29,12 +29,17 @@ pool = [torch.cuda.Stream() for _ in range(12)]
 ASSIGN = {"first set": None, "pool 0 1 2 3": (0, 1, 2, 3), "pool 4 5 6 7": (4, 5, 6, 7), "pool 1 2 3 4": (1, 2, 3, 4),
           "pool 0 4 1 5": (0, 4, 1, 5), "pool 0 1 4 5": (0, 1, 4, 5), "pool 0 1 2 2": (0, 1, 2, 2), "pool 0 2 4 6": (0, 2, 4, 6),
           "pool 8 9 10 11": (8, 9, 10, 11)}
+hi = [torch.cuda.Stream(priority=-1) for _ in range(4)]      # high-priority pool
+ASSIGN.update({"trunks high prio": ("h0", "h1", 2, 3), "trunks high, tail+head on pool 4 5": ("h0", "h1", 4, 5),
+               "tail+head high prio": (0, 1, "h2", "h3"), "all high prio": ("h0", "h1", "h2", "h3"),
+               "tail = side0's stream, head = side1's": ("f0", "f1", "f0", "f1")})
+pick = lambda i: (hi[int(i[1])] if i[0] == "h" else first[("side0", "side1")[int(i[1])]]) if isinstance(i, str) else pool[i]
 sets = {}
 for name, idx in ASSIGN.items():
     ws = dict(first)
     if idx is not None:
         for k, i in zip(("side0", "side1", "tail", "side_head"), idx):
-            ws[k] = pool[i]
+            ws[k] = pick(i)
     sets[name] = ws
 times = {n: [] for n in sets}
 for r in range(rounds + 1):
@@ -51,4 +56,4 @@ for r in range(rounds + 1):
 base = float(np.median(times["first set"]))
 for n in sets:
     md = float(np.median(times[n]))
-    print(f"{n:16s} {2 * bz / md:8.1f} hands/s ({100 * (base / md - 1):+5.2f} %)  best {2 * bz / min(times[n]):8.1f}")
+    print(f"{n:40s} {2 * bz / md:8.1f} hands/s ({100 * (base / md - 1):+5.2f} %)  best {2 * bz / min(times[n]):8.1f}")
