@@ -25,6 +25,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // nn.GELU() (exact, erf form): x * 0.5 * (1 + erf(x / sqrt(2)))
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -185,13 +186,19 @@ constexpr int SK_SLOT_FLOATS = 4 * 64 * 64;   // one workgroup's accumulators: 4
 // both operands are split on the way into LDS into three bf16 planes whose sum is the fp32 value exactly, and a
 // k-16 step is six v_mfma_f32_32x32x16_bf16 (the products b_i * b_j with i + j <= 2, fp32 accumulation): the
 // dropped terms are <= 2^-24 of a product -- fp32-grade results at 3/8 of the matrix-pipe time.
+// PREC 2 (HANDS_ACC_F64): the same fp32 operands and staging, but the fragments are widened to fp64 on their way out of LDS and
+// the products are accumulated by v_mfma_f64_16x16x4_f64 (a wave's 64 x 64 tile = 4 x 4 blocks, 128 accumulator registers, two
+// workgroups per CU, half the fp32 matrix rate): products of fp32 values are exact in fp64 and the sum carries 53 bits, so the
+// stored output is the correctly rounded fp32 of (sum + bias) -- no accumulation error at all.  For the few layers whose rounding
+// the network amplifies (handoccnet_light's heat-map head: DESIGN.md "Conditioning note"), not for throughput.
 // BLK > 0 (8 or 4 k-steps = 128 / 64 floats): blocked summation -- after every BLK k-steps the accumulators are added to a
 // second set and cleared, so no fp32 FMA chain is longer than the block (HANDS_SUM_BLOCK*; 64 more registers: these
 // instantiations run two workgroups per CU instead of four).
 template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool PRE = false, int BLK = 0>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int tile, int split, int kt0, int kt1,
                                           const float* acc_in, float* acc_out) {
-  constexpr int ROW = PREC ? LDS_ROW_B3 : LDS_ROW;
+  constexpr int ROW = PREC == 1 ? LDS_ROW_B3 : LDS_ROW;
+  constexpr bool F64 = PREC == 2;
   constexpr bool STEM = MODE == 1;
   constexpr bool DUAL = MODE == 2;
   constexpr int BM = 64 * WAVES_M;
@@ -307,7 +314,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
 
   // staging registers (explicit scalars-of-float4: arrays captured by lambdas ended up in scratch)
   float4 xr[A_ROWS], wr[W_ROWS];
-  static_assert(!PRE || (MODE == 2 && PREC == 0), "the input affine + LeakyReLU exists for exact-fp32 pointwise layers");
+  static_assert(!PRE || (MODE == 2 && PREC != 1), "the input affine + LeakyReLU exists for exact-fp32 pointwise layers");
   float4 psr = make_float4(1.f, 1.f, 1.f, 1.f), pbr = make_float4(0.f, 0.f, 0.f, 0.f);   // PRE: scale / shift of the staged k chunk
   // k-step state (wave-uniform for the regular path)
   int kh = 0, kw = 0, c0 = 0, woff = 0;
@@ -379,7 +386,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
         xr[i] = v;                                                                                  \
       }                                                                                             \
     }                                                                                               \
-    if constexpr (PREC == 0) {                                                                      \
+    if constexpr (PREC != 1) {                                                                      \
       float* dx = sX + (BUF) * BM * ROW + srow * ROW + swz_chunk * 4;                               \
       float* dw = sW + (BUF) * BN * ROW + srow * ROW + swz_chunk * 4;                               \
       _Pragma("unroll") for (int i = 0; i < A_ROWS; ++i)                                            \
@@ -394,6 +401,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
     }                                                                                               \
   } while (0)
 
+  f64x4 accd[F64 ? 4 : 1][F64 ? 4 : 1];    // PREC 2: [channel block][pixel block], D row = channel (lane >> 4) + 4 r, col = pixel lane & 15
+  if constexpr (F64) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) accd[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+  }
   f32x16 acc[2][2];
   if (acc_in != nullptr) {        // continue the FMA chain another workgroup started: same bits as an unsplit tile
     const float4* src = reinterpret_cast<const float4*>(acc_in) + (wave * 16) * 64 + lane;
@@ -433,8 +447,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
 
   // fragment read offsets: row = lane&31, k half = lane>>5
   // PREC 0: chunk (2 kk + half) of row r is stored at chunk ^ ((r >> 2) & 3); the kk = 1 fragment is the kk = 0 address ^ 32 B
-  const int frag = PREC ? (lane & 31) * ROW + (lane >> 5) * 4
-                        : (lane & 31) * ROW + (((lane >> 5) ^ ((lane >> 2) & 3)) * 4);
+  // PREC 2: row = lane & 15 of a 16-row block, 16-byte chunk lane >> 4 (MFMA t of a k-step takes k = 4 (lane >> 4) + t from both operands)
+  const int frag = PREC == 1 ? (lane & 31) * ROW + (lane >> 5) * 4
+                   : F64     ? (lane & 15) * ROW + (((lane >> 4) ^ ((lane >> 2) & 3)) * 4)
+                             : (lane & 31) * ROW + (((lane >> 5) ^ ((lane >> 2) & 3)) * 4);
   const float* fw = sW + (wn * 64) * ROW + frag;
   const float* fx = sX + (wm * 64) * ROW + frag;
   const float* fw1 = sW + (wn * 64) * ROW + (frag ^ 8);
@@ -442,7 +458,25 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
 
 #define COMPUTE_STEP(BUF)                                                                           \
   do {                                                                                              \
-    if constexpr (PREC == 0) {                                                               \
+    if constexpr (F64) {                                                                            \
+      float4 wf[4], xf[4]; /* [16-row block]: four consecutive k of the lane's row */                \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+        wf[i] = *reinterpret_cast<const float4*>(fw + (BUF) * BN * ROW + i * 16 * ROW);             \
+        xf[i] = *reinterpret_cast<const float4*>(fx + (BUF) * BM * ROW + i * 16 * ROW);             \
+      }                                                                                             \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                               \
+        double wd[4], xd[4];                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
+          wd[i] = (double)f4elem(wf[i], t);                                                         \
+          xd[i] = (double)f4elem(xf[i], t);                                                         \
+        }                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+            accd[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(wd[i], xd[j], accd[i][j], 0, 0, 0);   \
+          }                                                                                         \
+        }                                                                                           \
+      }                                                                                             \
+    } else if constexpr (PREC == 0) {                                                               \
       float4 wf[2][2], xf[2][2]; /* [32-row block][kk] */                                           \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                            \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                             \
@@ -483,6 +517,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
   } while (0)
 
   static_assert(BLK == 0 || ((BLK & (BLK - 1)) == 0 && PREC == 0), "block length: a power of two k-steps, exact fp32 only");
+  static_assert(!F64 || (WAVES_M == 2 && WAVES_N == 2), "fp64 accumulation: the 128 x 128 tile only");
   f32x16 tot[BLK ? 2 : 1][BLK ? 2 : 1];
   if constexpr (BLK > 0) {
 #pragma unroll
@@ -556,7 +591,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
     return;
   }
 #endif
-  if (!part && m0 + BM <= a.M && n0 + BN <= a.N) {      // (uniform) full tile: straight-line epilogue, activation compiled in
+  if (!F64 && !part && m0 + BM <= a.M && n0 + BN <= a.N) {      // (uniform) full tile: straight-line epilogue, activation compiled in
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int mw = m0 + (wave_u / WAVES_N) * 64, nw = n0 + (wave_u % WAVES_N) * 64;
     char* ou = reinterpret_cast<char*>(a.out) + ((size_t)mw * a.out_ps + nw) * 4;
@@ -572,19 +607,54 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
 #undef HANDS_EPI
     return;
   }
-  const float4 bv = part ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(a.bias + n_lane);
+  // PREC 2: the bias joins the fp64 sum before its one rounding (below), not the rounded value
+  const float4 bv = (part || F64) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(a.bias + n_lane);
+  double bd[F64 ? 4 : 1][F64 ? 4 : 1];
+  if constexpr (F64) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ch = n0 + wn * 64 + 16 * i + (lane >> 4) + 4 * r;
+        bd[i][r] = (!part && ch < a.N) ? (double)a.bias[ch] : 0.0;
+      }
+    if (part) {       // split-K slice of an fp64 launch: the partial sums stay fp64 ([ksplit][M][part_ps] doubles), reduced in fp64
+      double* pd = reinterpret_cast<double*>(a.partial) + (size_t)split * a.M * a.part_ps;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ch = n0 + wn * 64 + 16 * i + (lane >> 4) + 4 * r;
+            const int m = m0 + wm * 64 + 16 * jb + (lane & 15);
+            if (m < a.M && ch < a.N) pd[(size_t)m * a.part_ps + ch] = accd[i][jb][r];
+          }
+      return;
+    }
+  }
   const bool has_res = !part && a.res != nullptr;
   const int act = part ? HANDS_ACT_NONE : a.relu;
   float* const obase = part ? a.partial + (size_t)split * a.M * a.part_ps : a.out;
   const int ops = part ? a.part_ps : a.out_ps;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
+    if constexpr (F64) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            sE[(jj * 16 + (lane & 15)) * EROW + 16 * i + (lane >> 4) + 4 * r] = (float)(accd[i][2 * j + jj][r] + bd[i][r]);
+    } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<float4*>(sE + (lane & 31) * EROW + i * 32 + q * 8 + half * 4) =
             make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+    }
     const int mbase = m0 + wm * 64 + j * 32 + (lane >> 4);
     float4 rv[8];
 #pragma unroll
@@ -613,7 +683,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
 
 template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool PRE = false, int BLK = 0>
 __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
-  constexpr int RING = 2 * (64 * WAVES_M + 64 * WAVES_N) * (PREC ? LDS_ROW_B3 : LDS_ROW);
+  constexpr int RING = 2 * (64 * WAVES_M + 64 * WAVES_N) * (PREC == 1 ? LDS_ROW_B3 : LDS_ROW);
   __shared__ __attribute__((aligned(16))) float lds[RING > EPI_FLOATS ? RING : EPI_FLOATS];
   const int ntiles = a.nblk_m * a.nblk_n;
   const int split = a.ksplit > 1 ? blockIdx.x / ntiles : 0;
@@ -723,6 +793,7 @@ int launch(ConvArgs& a, hipStream_t stream) {
 template <int MODE, bool PRE = false>
 int launch_fp32(const hands_conv_desc* d, ConvArgs& a, hipStream_t s) {
   const bool narrow = d->Cout <= 64;
+  if (d->act & HANDS_ACC_F64) return launch<2, 2, MODE, 2, PRE>(a, s);
   if (d->act & HANDS_SUM_BLOCK128) return narrow ? launch<4, 1, MODE, 0, PRE, 8>(a, s) : launch<2, 2, MODE, 0, PRE, 8>(a, s);
   if (d->act & HANDS_SUM_BLOCK64) return narrow ? launch<4, 1, MODE, 0, PRE, 4>(a, s) : launch<2, 2, MODE, 0, PRE, 4>(a, s);
   return narrow ? launch<4, 1, MODE, 0, PRE>(a, s) : launch<2, 2, MODE, 0, PRE>(a, s);
@@ -819,6 +890,25 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, i
   }
 }
 
+// the same for an fp64 launch (HANDS_ACC_F64): fp64 partial sums, bias added in fp64, ONE rounding, then residual + activation in fp32
+__global__ void splitk_reduce_f64_kernel(const double* __restrict__ partial, int S, int M, int N, int part_ps,
+                                         const float* __restrict__ bias, const float* res, int res_ps, float* out, int out_ps,
+                                         int act) {
+  const long long total = (long long)M * N;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % N);
+    const long long m = i / N;
+    double v = partial[m * part_ps + n];
+    for (int s = 1; s < S; ++s) v += partial[((long long)s * M + m) * part_ps + n];
+    float f = (float)(v + (double)bias[n]);
+    if (res) f += res[m * res_ps + n];
+    if (act == HANDS_ACT_RELU) f = fmaxf(f, 0.f);
+    else if (act == HANDS_ACT_GELU) f = gelu_erf(f);
+    else if (act == HANDS_ACT_LEAKY_RELU) f = f > 0.f ? f : 0.01f * f;
+    out[m * out_ps + n] = f;
+  }
+}
+
 // split-K policy: depends on the layer (N, K) and on M only through a fixed threshold, so that the
 // summation order -- hence every output bit -- is the same for every batch size below the threshold
 int splitk_factor(const hands_conv_desc* d) {
@@ -837,7 +927,8 @@ bool conv_geometry_ok(const hands_conv_desc* d) {
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 ||
       d->pad < 0)
     return false;
-  if ((d->act & HANDS_ACT_MASK) > HANDS_ACT_LEAKY_RELU || (d->act & ~(HANDS_ACT_MASK | HANDS_MATH_BF16X3 | HANDS_SUM_BLOCK128 | HANDS_SUM_BLOCK64))) return false;   // unknown code
+  if ((d->act & HANDS_ACT_MASK) > HANDS_ACT_LEAKY_RELU || (d->act & ~(HANDS_ACT_MASK | HANDS_MATH_BF16X3 | HANDS_SUM_BLOCK128 | HANDS_SUM_BLOCK64 | HANDS_ACC_F64))) return false;   // unknown code
+  if ((d->act & HANDS_ACC_F64) && ((d->act & (HANDS_MATH_BF16X3 | HANDS_SUM_BLOCK128 | HANDS_SUM_BLOCK64)) || d->Cin == 4)) return false;
   if ((d->act & HANDS_SUM_BLOCK128) && (d->act & (HANDS_SUM_BLOCK64 | HANDS_MATH_BF16X3))) return false;          // one summation form
   if ((d->act & HANDS_SUM_BLOCK64) && (d->act & HANDS_MATH_BF16X3)) return false;
   if (d->Cin % 4 || d->Cout % 4 || d->Kpad % BK || d->Kpad < d->KH * d->KW * d->Cin) return false;
@@ -876,7 +967,7 @@ extern "C" long long hands_conv2d_workspace_floats(const hands_conv_desc* d, int
   if (S <= 0) S = splitk_factor(d);
   if (S > d->Kpad / BK) S = d->Kpad / BK;
   if (S <= 1) return 0;
-  return (long long)S * d->B * d->Ho * d->Wo * d->Cout;
+  return (long long)S * d->B * d->Ho * d->Wo * d->Cout * ((d->act & HANDS_ACC_F64) ? 2 : 1);   // fp64 partial sums
 }
 
 extern "C" int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
@@ -930,7 +1021,7 @@ extern "C" int hands_conv2d_nhwc_streamk_f32(const hands_conv_desc* d, const flo
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
   a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
-  if (d->act & (HANDS_MATH_BF16X3 | HANDS_SUM_BLOCK128 | HANDS_SUM_BLOCK64))
+  if (d->act & (HANDS_MATH_BF16X3 | HANDS_SUM_BLOCK128 | HANDS_SUM_BLOCK64 | HANDS_ACC_F64))
     return hands_conv2d_nhwc_f32(d, in, w_packed, bias, residual, out, stream);
   a.relu = d->act & HANDS_ACT_MASK;
   a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.pre_scale = nullptr; a.pre_shift = nullptr;
@@ -988,7 +1079,8 @@ int splitk_launch(const hands_conv_desc* d, const float* in, const float* w_pack
   const long long M = (long long)d->B * d->Ho * d->Wo;
   const int part_ps = d->Cout;                          // Cout % 4 == 0
   if (S > d->Kpad / BK) S = d->Kpad / BK;
-  if (S <= 1 || !workspace || workspace_floats < (long long)S * M * part_ps)
+  const bool f64 = (d->act & HANDS_ACC_F64) != 0;       // fp64 accumulation: the partial sums are doubles (twice the workspace)
+  if (S <= 1 || !workspace || workspace_floats < (long long)S * M * part_ps * (f64 ? 2 : 1) || (f64 && (((uintptr_t)workspace) & 7)))
     return pre ? pre_launch(d, in, pre_scale, pre_shift, w_packed, bias, residual, out, stream)
                : hands_conv2d_nhwc_f32(d, in, w_packed, bias, residual, out, stream);
   if (!in || !w_packed || !bias || !out || !conv_geometry_ok(d) || S > 64) return HANDS_EINVAL;
@@ -1010,6 +1102,12 @@ int splitk_launch(const hands_conv_desc* d, const float* in, const float* w_pack
   else if (pointwise_route_ok(d)) rc = launch_fp32<2>(d, a, s);
   else rc = launch_fp32<0>(d, a, s);
   if (rc) return rc;
+  if (f64) {
+    hipLaunchKernelGGL(splitk_reduce_f64_kernel, dim3(hands_grid_1d(M * d->Cout, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const double*>(workspace), S, (int)M, d->Cout, part_ps, bias, residual, d->res_pix_stride,
+                       out, d->out_pix_stride, d->act & HANDS_ACT_MASK);
+    return (int)hipGetLastError();
+  }
   const long long total = M * (d->Cout / 4);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(hands_grid_1d(total, 256)), dim3(256), 0, s, workspace, S, (int)M,
                      d->Cout / 4, part_ps, bias, residual, d->res_pix_stride, out, d->out_pix_stride, d->act & HANDS_ACT_MASK);

@@ -66,6 +66,7 @@ struct Wino4Args {
   int B, H, W, Cin, Cout, nh, nw;
   int in_ps, out_ps, act;
   int nblk_m, nblk_n, nseg;
+  int band;                         // channel blocks per band of the workgroup order (w4_launch_nob)
   int rows;                         // B * nh flattened tile rows
   uint32_t nh_mul, nh_sh;           // magic number: x / nh
 };
@@ -119,6 +120,7 @@ struct W4Geom {
 
 constexpr int W4_VBUF = 36 * 1024;                              // [f 36][tile 32][8 channels] fp32
 constexpr int W4_PATCH_MAX = 36 * 1024;
+constexpr long long W4_BAND_BYTES = 2560 * 1024;                // weights of one band of channel blocks: inside an XCD's 4 MB L2
 
 // Second half of A^T M A for 32 output channels whose folded blocks sit in the LDS (8 channels per 36 KB region), all 16 waves:
 // thread = (8-channel group rd, output column j, tile, channel quad).  Column j of Z = M A:
@@ -196,10 +198,19 @@ __global__ void __launch_bounds__(1024, 1) conv_wino4_f32_kernel(Wino4Args a) {
   constexpr int VM = (1 << VSH) - 1;
 
   // ---- which tiles, which 32 output channels (wave-uniform) -----------------------------------------------------------------
-  // order: all tile blocks of channel block 0, then channel block 1, ...: the weights of one block (<= 2.4 MB at Cin = 512)
-  // stay in the XCD's L2 while the (small) input of a deep layer is re-read per block
+  // order (round 6): BANDS of `band` channel blocks whose weights fit an XCD's L2 together (<= 2.4 MB: all of layer1 / layer2, two
+  // blocks of layer3, one of layer4); inside a band the channel block is the FASTEST index, so the workgroups that read the same
+  // tile block's patches sit next to each other in one XCD's contiguous range and the activations cross the fabric once per band
+  // instead of once per channel block (round 5 order = band 1: FETCH_SIZE showed Cout / 32 x the input per launch)
   const int wg = w4_xcd_remap(blockIdx.x, a.nblk_m * a.nblk_n);
-  const int nbg = wg / a.nblk_m, mb = wg - nbg * a.nblk_m;
+  int nbg, mb;
+  {
+    const int full = a.nblk_n / a.band, per = a.band * a.nblk_m;
+    int bi = wg / per, r = wg - bi * per, bw = a.band;
+    if (bi >= full) { bi = full; r = wg - full * per; bw = a.nblk_n - full * a.band; }     // the last, narrower band
+    mb = r / bw;
+    nbg = bi * a.band + (r - mb * bw);
+  }
   const int nb = nbg * NOB;                                     // first 32-channel block of this workgroup
   int R0, s0, tx0;
   if constexpr (LINEAR) {
@@ -516,6 +527,14 @@ static int w4_launch_nob(Wino4Args& a, hipStream_t stream) {
     nblk_m = (rows + G::NR - 1) / G::NR * a.nseg;
   }
   a.nblk_n = a.Cout / (32 * NOB);                                // workgroups along the channels
+  {
+    // a workgroup's weights: Cin / 8 stages x 36 KB per 32 channels
+    const long long wbytes = (long long)(a.Cin / 8) * 36864 * NOB;
+    long long band = W4_BAND_BYTES / wbytes;
+    const char* env = getenv("HANDS_W4_BAND");                   // dev override (tools/experiments): 1 = the round-5 order
+    if (env && atoi(env) > 0) band = atoi(env);
+    a.band = (int)(band < 1 ? 1 : (band > a.nblk_n ? a.nblk_n : band));
+  }
   if (nblk_m <= 0 || nblk_m * a.nblk_n > 0x7fffffffLL) return HANDS_EINVAL;
   a.nblk_m = (int)nblk_m;
   const long long nwg = nblk_m * a.nblk_n;        // one workgroup (16 waves, the whole LDS) per CU at a time
@@ -568,7 +587,7 @@ extern "C" int hands_conv3x3_winograd4_f32(const hands_conv_desc* d, const float
   a.nh = (d->H + 3) / 4; a.nw = (d->W + 3) / 4;
   a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.act = d->act & HANDS_ACT_MASK;
   a.rows = d->B * a.nh;
-  a.nblk_m = a.nblk_n = a.nseg = 0;
+  a.nblk_m = a.nblk_n = a.nseg = 0; a.band = 1;
   hipStream_t s = (hipStream_t)stream;
   if (a.nw == 7) return w4_launch<7, true>(a, s);
   if (a.nw == 14) return w4_launch<7, true, 1>(a, s);

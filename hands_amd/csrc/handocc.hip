@@ -192,7 +192,7 @@ __global__ void upsample_nearest2x_add_kernel(const float4* __restrict__ low, co
 __global__ void __launch_bounds__(256) spatial_softmax_kernel(const float* __restrict__ lat, int ld_in,
                                                               const float* __restrict__ betas, float* __restrict__ out,
                                                               int ld_out, int N, int J) {
-  __shared__ float red[8];
+  __shared__ double red[8];
   const int b = blockIdx.y, j = blockIdx.x, tid = threadIdx.x;
   float* o = out + (long long)b * N * ld_out + j;
   if (j >= J) {
@@ -200,22 +200,25 @@ __global__ void __launch_bounds__(256) spatial_softmax_kernel(const float* __res
     return;
   }
   const float* p = lat + (long long)b * N * ld_in + j;
-  const float beta = betas[j];
-  float mx = -INFINITY;
-  for (int t = tid; t < N; t += 256) mx = fmaxf(mx, p[(long long)t * ld_in] * beta);
+  // fp64 inside (round 6): this softmax is where handoccnet_light amplifies rounding most (the logits reach +-50: an fp32
+  // product latent * beta alone moves a probability by |x| 2^-24 relative, tools/hon_error_stages.py), and it is 21 x 1024
+  // values per crop -- the exact product, exp and sum in fp64, ONE rounding of each probability
+  const double beta = (double)betas[j];
+  double mx = -INFINITY;
+  for (int t = tid; t < N; t += 256) mx = fmax(mx, (double)p[(long long)t * ld_in] * beta);
 #pragma unroll
-  for (int s = 32; s > 0; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
+  for (int s = 32; s > 0; s >>= 1) mx = fmax(mx, __shfl_xor(mx, s));
   if ((tid & 63) == 0) red[tid >> 6] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  float sum = 0.f;
-  for (int t = tid; t < N; t += 256) sum += expf(p[(long long)t * ld_in] * beta - mx);
+  mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  double sum = 0.0;
+  for (int t = tid; t < N; t += 256) sum += exp((double)p[(long long)t * ld_in] * beta - mx);
 #pragma unroll
   for (int s = 32; s > 0; s >>= 1) sum += __shfl_xor(sum, s);
   if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
   __syncthreads();
   sum = (red[4] + red[5]) + (red[6] + red[7]);
-  for (int t = tid; t < N; t += 256) o[(long long)t * ld_out] = expf(p[(long long)t * ld_in] * beta - mx) / sum;
+  for (int t = tid; t < N; t += 256) o[(long long)t * ld_out] = (float)(exp((double)p[(long long)t * ld_in] * beta - mx) / sum);
 }
 
 // ---- flash attention on fp32 MFMA: N tokens (multiple of 128), head dim 64 ---------------------------
@@ -355,16 +358,24 @@ __global__ void __launch_bounds__(256, 2) flash_attention64_kernel(const float* 
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    // P V in blocks of 32 keys (round 6): each block's product starts from zero and joins the running output by ONE add, so
+    // no fp32 chain is longer than 32 keys + the 32 block sums of a row (one 1024-key FMA chain per output before: the FIT / SET
+    // outputs sat 2-2.5x farther from an fp64 evaluation than a path with exact convolutions needs -- tools/hon_error_stages.py)
 #pragma unroll
     for (int kbk = 0; kbk < 4; ++kbk) {
+      f32x16 t0, t1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { t0[r] = 0.f; t1[r] = 0.f; }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         // register r of block kbk holds P for key kbk * 32 + 8 (r >> 2) + (r & 3) + 4 half
         const float* vp = vrd + (kbk * 32 + 8 * (r >> 2) + (r & 3)) * D;
         const float a0 = vp[0], a1 = vp[32];
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, s[kbk][r], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[kbk][r], o[1], 0, 0, 0);
+        t0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, s[kbk][r], t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[kbk][r], t1, 0, 0, 0);
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o[0][r] += t0[r]; o[1][r] += t1[r]; }
     }
   }
 #undef ISSUE_TILE

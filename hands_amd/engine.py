@@ -17,6 +17,7 @@ from ._lib import ConvDesc, check, ptr
 
 MATH_BF16X3 = 0x100   # HANDS_MATH_BF16X3 (include/hands_hip.h)
 _SUM_BLOCK = {128: 0x200, 64: 0x400}   # HANDS_SUM_BLOCK128 / HANDS_SUM_BLOCK64
+ACC_F64 = 0x800                        # HANDS_ACC_F64
 
 
 class ConvEngine:
@@ -58,6 +59,11 @@ class ConvEngine:
         self.chain_in_kernel = False  # True (chain_limit 128 or 64 only): the blocks are summed INSIDE the launch (desc.act |=
                                       # HANDS_SUM_BLOCK128 / 64: a second accumulator set, no workspace, no reduce launch) instead
                                       # of through split-K; launches that are split for another reason block each slice
+        self.acc64 = True             # honour PackedConv.acc64: layers a model marked run with fp64 accumulation (HANDS_ACC_F64:
+                                      # v_mfma_f64_16x16x4_f64, correctly rounded fp32 outputs, half the fp32 matrix rate) -- ONE plain
+                                      # direct launch, never Winograd / split-K / stream-K / blocked.  HandOccNet marks its heat-map head,
+                                      # encoder and MLPs (DESIGN.md "Conditioning note"); False = those layers take the fp32 routes
+        self.last_acc64 = False       # the launch the hook is being called for accumulates in fp64
         self.hook = None              # callable(phase, pc, npix, stream_handle, has_res, kernel): bench.py brackets
                                       # every MFMA launch (conv_igemm and the fused stem) with events; `kernel` is the
                                       # kernel the launch really runs (conv_igemm_f32_kernel / conv_igemm_sk_f32_kernel =
@@ -75,7 +81,7 @@ class ConvEngine:
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
         for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "winograd", "winograd4", "fuse_mano", "fuse_pre", "stream_k", "math", "chain_limit",
-                  "chain_min_k", "chain_max_pix", "chain_skip_tokens", "chain_in_kernel"):
+                  "chain_min_k", "chain_max_pix", "chain_skip_tokens", "chain_in_kernel", "acc64"):
             setattr(e, k, getattr(self, k))
         return e
 
@@ -140,6 +146,7 @@ class ConvEngine:
                      pc.Kpad, int(relu) | (MATH_BF16X3 if self.math == "bf16x3" else 0))   # relu: bool or a HANDS_ACT_* code
         hook = self.hook
         self.last_sum_block = 0
+        acc64 = self.last_acc64 = bool(self.acc64 and pc.acc64 and self.math == "fp32" and pc.Cin != 4)
         S = L.hands_conv2d_splitk_factor(C.byref(d)) if (splitk and self.use_splitk) else 1
         if splitk_n > 1 and self.use_splitk:
             S = splitk_n
@@ -149,8 +156,13 @@ class ConvEngine:
             bm, bn = (256, 64) if pc.Cout <= 64 else (128, 128)
             tiles = -(-(B * Ho * Wo) // bm) * -(-pc.Cout // bn)
             S = max(S, min(256 // tiles, pc.Kpad // 128, 32)) if tiles <= 128 else S
+        if acc64:               # direct launch(es); a split keeps fp64 partial sums (per-sample head GEMMs, call-site constants)
+            d.act |= ACC_F64
+            S = (L.hands_conv2d_splitk_factor(C.byref(d)) if (splitk and self.use_splitk) else 1)
+            if splitk_n > 1 and self.use_splitk:
+                S = splitk_n
         rp = ptr(res, res_off) if res is not None else None
-        if (self.winograd and self.winograd4 and pc.wino4 is not None and res is None and pre is None and S <= 1
+        if (not acc64 and self.winograd and self.winograd4 and pc.wino4 is not None and res is None and pre is None and S <= 1
                 and self.math == "fp32" and (ptr(x, x_off) | ptr(out, out_off)) % 16 == 0
                 and L.hands_conv3x3_winograd4_supported(C.byref(d))):
             if hook is not None:
@@ -161,7 +173,7 @@ class ConvEngine:
             if hook is not None:
                 hook("end", pc, B * Ho * Wo, stream, False, "conv_wino4_f32_kernel")
             return Ho, Wo
-        if (self.winograd and pc.wino is not None and res is None and pre is None and S <= 1 and self.math == "fp32"
+        if (not acc64 and self.winograd and pc.wino is not None and res is None and pre is None and S <= 1 and self.math == "fp32"
                 and (ptr(x, x_off) | ptr(out, out_off)) % 16 == 0        # its accesses are 16 bytes wide
                 and L.hands_conv3x3_winograd_supported(C.byref(d))):
             if hook is not None:
@@ -172,7 +184,7 @@ class ConvEngine:
             if hook is not None:
                 hook("end", pc, B * Ho * Wo, stream, False, "conv_wino_f32_kernel")
             return Ho, Wo
-        if (self.chain_limit and self.use_splitk and self.math == "fp32"
+        if (self.chain_limit and not acc64 and self.math == "fp32" and (self.chain_in_kernel or self.use_splitk)
                 and pc.Kpad >= max(2 * self.chain_limit, self.chain_min_k)
                 and (not self.chain_max_pix or Ho * Wo <= self.chain_max_pix)
                 and not (self.chain_skip_tokens and H * W == 1 and B >= 4096)):
@@ -197,7 +209,7 @@ class ConvEngine:
             if hook is not None:
                 hook("end", pc, B * Ho * Wo, stream, res is not None, kname)
             return Ho, Wo
-        use_sk = S <= 1 and self.math == "fp32" and ((not self.overlap) if self.stream_k == "auto" else self.stream_k) and \
+        use_sk = S <= 1 and not acc64 and self.math == "fp32" and ((not self.overlap) if self.stream_k == "auto" else self.stream_k) and \
             not (d.act & (_SUM_BLOCK[64] | _SUM_BLOCK[128])) and \
             L.hands_conv2d_streamk_grid(C.byref(d)) > 0 and not self._capturing(L, stream)
         # (a blocked launch keeps the plain kernel: stream-K continues ONE chain across workgroups)

@@ -34,6 +34,26 @@ HANDOCC_DEFAULT_ARGS = _Args(pos_enc="center+corner_latent", n_freq_pos_enc=4, u
                              use_render_seg_loss=False, img_res=224, focal_length=1000.0,
                              method="handoccnet_light")
 NTOK, CF, HEADS = 1024, 256, 4
+STAGES = ("resnet", "fpn", "fit", "set", "hourglass", "reghead", "encoder", "mlp")
+
+
+def stage_of(p: str) -> str:
+    """Stage of a reference parameter prefix: the units ``HandOccNet.acc64_stages`` is expressed in."""
+    if p.startswith("backbone.layer"):
+        return "resnet"                    # backbone.py:68-119 (stem + the four stages)
+    if p.startswith("backbone."):
+        return "fpn"                       # backbone.py:54-62 laterals / smoothing, cbam.py:72-82 gate
+    if p.startswith("FIT"):
+        return "fit"
+    if p.startswith("SET"):
+        return "set"
+    if ".hand_regHead.hg" in p:
+        return "hourglass"                 # hand_head.py:217-235
+    if ".hand_regHead" in p:
+        return "reghead"                   # hand_head.py:75-94: res unit, fc, score -> the heat-map logits
+    if ".hand_Encoder" in p:
+        return "encoder"                   # hand_head.py:266-280
+    return "mlp"                           # mano_head.py:190-207, the KPE MLP, the grasp classifier
 
 
 def _conv_fns(L, stream, new, engine, small_map_splitk=True):
@@ -104,6 +124,7 @@ class HandOccNet(EngineSwitches, nn.Module):
         self.engine.winograd = True
         self.winograd_scope = "all"        # "all" | "backbone+fit" | "backbone" (trunk + FPN smoothing) | "trunk"
         self.engine.chain_limit, self.engine.chain_min_k, self.engine.chain_in_kernel = 64, 0, True
+        self.acc64_stages = frozenset()    # stages (STAGES) whose convolutions / linear layers accumulate in fp64 (HANDS_ACC_F64)
         self.small_map_splitk = False  # True / "deep" / "16x16": call-site constant split-K on maps of <= 8x8 pixels and on the
                                        # one-tile 16x16 layers (see _conv_fns).  Off since round 5: with three forwards in flight the
                                        # chip is filled by other forwards, and the reduce launches cost more than the slices gain
@@ -162,10 +183,14 @@ class HandOccNet(EngineSwitches, nn.Module):
             sc = self.winograd_scope
             wino = (sc == "all" or (sc == "trunk" and p.startswith("backbone.layer")) or
                     (sc in ("backbone", "backbone+fit") and p.startswith("backbone.")) or (sc == "backbone+fit" and p.startswith("FIT.")))
-            return pack_conv(w, b, stride, pad, dev, cin_pad_to=cin_pad_to, winograd=wino)
+            pc = pack_conv(w, b, stride, pad, dev, cin_pad_to=cin_pad_to, winograd=wino)
+            pc.acc64 = stage_of(p) in self.acc64_stages
+            return pc
 
         def lin(p, **kw):
-            return pack_linear(sd[p + ".weight"], sd[p + ".bias"], dev, **kw)
+            pc = pack_linear(sd[p + ".weight"], sd[p + ".bias"], dev, **kw)
+            pc.acc64 = stage_of(p) in self.acc64_stages and not p.startswith("grasp")
+            return pc
 
         def preact(p):
             s, t = bn_affine(p)
@@ -233,6 +258,7 @@ class HandOccNet(EngineSwitches, nn.Module):
         bd = torch.cat([sd[mp + ".pose_reg.bias"], sd[mp + ".shape_reg.bias"], sd[mp + ".cam_reg.bias"]], 0)
         rows = list(range(96)) + [96 + i for i in range(10)] + [108 + i for i in range(3)]
         P["regs"] = pack_linear(wd, bd, dev, row_index=rows, n_total=112)
+        P["regs"].acc64 = "mlp" in self.acc64_stages
         if self.use_grasp_loss:
             gcol = [144 + i for i in range(10)] + list(range(144))
             P["g0"] = lin("grasp_classifier.0", col_index=gcol, k_total=154)

@@ -87,6 +87,14 @@ typedef struct hands_conv_desc {
  * the plain launch.  At most one of the two, and not together with HANDS_MATH_BF16X3 (HANDS_EINVAL). */
 #define HANDS_SUM_BLOCK128 0x200
 #define HANDS_SUM_BLOCK64 0x400
+/* fp64 accumulation, OR'ed into desc.act (round 6): the same fp32 operands, products accumulated by v_mfma_f64_16x16x4_f64 and the
+ * bias added in fp64 -- the stored value is the correctly rounded fp32 of (sum + bias), then residual and activation in fp32 as the
+ * reference's separate statements do.  Half the fp32 matrix rate: for the few layers whose rounding a network amplifies
+ * (handoccnet_light's heat-map head, hand_head.py:75-94,266-280), not for throughput.  Batch-size invariant and deterministic.
+ * Honoured by hands_conv2d_nhwc_f32, hands_conv2d_nhwc_pre_f32 and the split-K entries (the partial sums are fp64 there:
+ * hands_conv2d_workspace_floats doubles, the workspace must be 8-byte aligned); the stream-K entry runs it as ONE plain launch;
+ * not for the RGB0 stem (Cin == 4) and not together with the flags above (HANDS_EINVAL). */
+#define HANDS_ACC_F64 0x800
 
 int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
                           const float* bias, const float* residual, float* out,

@@ -1058,7 +1058,7 @@ def test_summation_flags_are_exclusive_and_chain_in_kernel_rejects_other_lengths
     pc = pack_conv(torch.randn(128, 256, 1, 1, generator=g) / 16, torch.randn(128, generator=g), 1, 0, DEV)
     x = torch.randn(4, 8, 8, 256, generator=g).to(DEV)
     out = torch.full((4, 8, 8, 128), float("nan"), device=DEV)
-    for flags in (0x200 | 0x400, 0x200 | 0x100, 0x400 | 0x100, 0x800):
+    for flags in (0x200 | 0x400, 0x200 | 0x100, 0x400 | 0x100, 0x800 | 0x100, 0x800 | 0x200, 0x800 | 0x400, 0x1000):
         d = _lib.ConvDesc(4, 8, 8, 256, 8, 8, 128, 1, 1, 1, 0, 256, 128, 0, pc.Kpad, 1 | flags)
         assert L.hands_conv2d_nhwc_f32(C.byref(d), ptr(x), ptr(pc.w), ptr(pc.bias), None, ptr(out), _stream()) == 10001, hex(flags)
     torch.cuda.synchronize()
@@ -1072,6 +1072,75 @@ def test_summation_flags_are_exclusive_and_chain_in_kernel_rejects_other_lengths
     eng.conv(L, pc, x, 4, 8, 8, out, 1, _stream())
     torch.cuda.synchronize()
     assert torch.isfinite(out).all() and eng.last_sum_block == 128
+
+
+ACC64_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, act, residual, pre
+    (3, 256, 32, 32, 128, 1, 1, 0, 3, False, True),      # a pre-activation unit's conv1 (hand_head.py:170-172)
+    (3, 128, 32, 32, 128, 3, 1, 1, 3, False, False),     # its 3x3 (direct, never Winograd)
+    (3, 128, 32, 32, 256, 1, 1, 0, 0, True, False),      # its conv3 + skip
+    (2, 256, 32, 32, 24, 1, 1, 0, 0, False, False),      # the score layer: 21 + 3 channels, one partial n-tile
+    (5, 16, 9, 11, 12, 3, 1, 1, 1, True, False),         # odd sizes, partial m- and n-tiles
+    (2, 64, 14, 14, 128, 3, 2, 1, 1, False, False),      # strided
+    (70, 1024, 1, 1, 1024, 1, 1, 0, 3, False, False),    # a per-sample MLP row block (mano_head.py:190-207), split-K asked for
+    (2, 1024, 7, 7, 512, 3, 1, 0, 1, False, False),      # K = 9216 without padding
+]
+
+
+@pytest.mark.parametrize("case", ACC64_CASES)
+def test_fp64_accumulation_is_correctly_rounded(case):
+    """PackedConv.acc64 (desc.act | HANDS_ACC_F64): products accumulated by v_mfma_f64_16x16x4_f64, bias added in fp64, ONE rounding
+    to fp32, then residual and activation in fp32.  Every output equals the fp32 rounding of an fp64 convolution (the k order only
+    matters at 1e-16), it is a direct launch whatever Winograd / blocking the engine would otherwise choose (split-K keeps fp64
+    partial sums), and it is bit-reproducible and batch-size invariant."""
+    B, Cin, H, W, Cout, k, stride, pad, act, use_res, use_pre = case
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(sum(case))
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    pc = pack_conv(w, torch.randn(Cout, generator=g), stride, pad, DEV)
+    pc.acc64 = True
+    x = torch.randn(B, H, W, Cin, generator=g).to(DEV)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Ho, Wo, pc.Cout, generator=g).to(DEV) if use_res else None
+    pre = (torch.rand(Cin, generator=g).to(DEV) + 0.5, torch.randn(Cin, generator=g).to(DEV) * 0.1) if use_pre else None
+    kernels = []
+
+    def run(xs=x, rs=res, acc64=True):
+        eng = ConvEngine()
+        eng.acc64 = acc64
+        eng.chain_limit, eng.chain_in_kernel = 64, True              # HandOccNet's engine settings: none may apply to a marked layer
+        eng.hook = lambda phase, pc_, npix, st, has_res, kernel: kernels.append((kernel, eng.last_acc64)) if phase == "begin" else None
+        out = torch.full((xs.shape[0], Ho, Wo, pc.Cout), float("nan"), device=DEV)
+        eng.conv(L, pc, xs, xs.shape[0], H, W, out, act, _stream(), res=rs, splitk=(H * W == 1), pre=pre)
+        torch.cuda.synchronize()
+        return out
+
+    out = run()
+    # a per-sample row block is cut by the library's layer-only split-K policy: its partial sums stay fp64
+    assert kernels[-1] == ("conv_igemm_splitk_f32_kernel" if H * W == 1 else "conv_igemm_f32_kernel", True)
+    assert torch.equal(run(), out)
+    nb = max(1, B // 3)
+    assert torch.equal(run(x[:nb].contiguous(), res[:nb].contiguous() if use_res else None), out[:nb])
+    xin = x.cpu()
+    if use_pre:
+        xin = F.leaky_relu(xin * pre[0].cpu() + pre[1].cpu(), 0.01)          # fp32, as the staging path computes it
+    ref = F.conv2d(xin.permute(0, 3, 1, 2).double(), w.double(), pc.bias[:Cout].double().cpu(), stride=stride, padding=pad).float()
+    if res is not None:
+        ref = ref + res.cpu().permute(0, 3, 1, 2)[:, :Cout]
+    ref = {0: ref, 1: F.relu(ref), 3: F.leaky_relu(ref, 0.01)}[act]
+    got = out.cpu().permute(0, 3, 1, 2)[:, :Cout]
+    assert torch.isfinite(got).all()
+    mism = (got != ref)
+    # an fp64 sum in another order differs at 1e-16 relative: a different fp32 rounding needs a tie within that distance
+    assert mism.float().mean().item() < 1e-5, mism.float().mean().item()
+    assert (got - ref).abs().max().item() <= 2.4e-7 * max(1.0, ref.abs().max().item())
+    plain = run(acc64=False).cpu().permute(0, 3, 1, 2)[:, :Cout]            # the engine switch turns the marks off
+    assert kernels[-1][1] is False
+    e64 = F.conv2d(xin.permute(0, 3, 1, 2).double(), w.double(), pc.bias[:Cout].double().cpu(), stride=stride, padding=pad)
+    if res is not None:
+        e64 = e64 + res.cpu().permute(0, 3, 1, 2)[:, :Cout].double()
+    e64 = {0: e64, 1: F.relu(e64), 3: F.leaky_relu(e64, 0.01)}[act]
+    assert (got.double() - e64).abs().mean().item() <= (plain.double() - e64).abs().mean().item()
 
 
 @pytest.mark.parametrize("name", SWITCH_CASES)

@@ -9,7 +9,8 @@ processes (8 threads each) created before the parent touches the GPU.
 
 usage: python tools/hon_parity_ab.py [--seeds N] [--first S] [--arms a,b,...] [--workers W] [--out gpurun_out/hon_ab.json]
        [--speed]   (hands/s of every arm at bz = 32 and 256, shipped pipelined mode)
-arm syntax: <scope>[+c<chain_limit>[k<chain_min_k>][p<chain_max_pix>][t = token GEMMs unblocked][i = blocks summed inside the launch]], scope in direct | trunk | backbone | backbone+fit | all
+arm syntax: <scope>[+c...][+f:stage.stage...] (stages accumulated in fp64: resnet fpn fit set hourglass reghead encoder mlp, or ALL)
+            <scope>[+c<chain_limit>[k<chain_min_k>][p<chain_max_pix>][t = token GEMMs unblocked][i = blocks summed inside the launch]], scope in direct | trunk | backbone | backbone+fit | all
 """
 import argparse
 import json
@@ -60,6 +61,7 @@ def wilson(k, n, z=1.96):
 
 
 def parse_arm(name):
+    name, _, f64 = name.partition("+f:")           # "+f:reghead.encoder.mlp": stages accumulated in fp64
     scope, _, rest = name.partition("+c")
     limit = min_k = max_pix = 0
     skip_tok, in_kernel = "t" in rest, "i" in rest
@@ -68,7 +70,7 @@ def parse_arm(name):
         rest, _, mp = rest.partition("p")
         lim, _, mk = rest.partition("k")
         limit, min_k, max_pix = int(lim), int(mk or 0), int(mp or 0)
-    return scope, limit, min_k, max_pix, skip_tok, in_kernel
+    return scope, limit, min_k, max_pix, skip_tok, in_kernel, frozenset(x for x in f64.split(".") if x)
 
 
 def main():
@@ -107,8 +109,9 @@ def main():
     from hands_amd.weights import synthetic_inputs
     models = {}
     for name in arms:
-        scope, limit, min_k, max_pix, skip_tok, in_kernel = parse_arm(name)
+        scope, limit, min_k, max_pix, skip_tok, in_kernel, f64 = parse_arm(name)
         m = hands_amd.apply_recipe(hands_amd.HandOccNet()).to("cuda").eval()
+        m.acc64_stages = f64 if "ALL" not in f64 else frozenset(hands_amd.handoccnet.STAGES)
         m.engine.winograd = scope != "direct"
         m.winograd_scope = scope if scope != "direct" else "backbone"
         m.engine.chain_limit, m.engine.chain_min_k, m.engine.chain_max_pix = limit, min_k, max_pix
