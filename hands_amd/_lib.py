@@ -109,6 +109,7 @@ SIGNATURES = {
     "hands_upsample_nearest2x_add_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
     "hands_spatial_softmax_f32": [_P, _I, _P, _P, _I, _I, _I, _I, _P],
     "hands_flash_attention_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "hands_ceiling_hbm_read_f32": [_P, C.c_longlong, _P, _P],
     "hands_eval_metrics_f32": [C.POINTER(EvalIn), C.POINTER(EvalOut), _I, _P],
     "hands_mano_pose_aa_f32": [C.POINTER(ManoConsts), _P, _P, _I, _P, _I, _P, _P, _I, _P],
     "hands_gt_targets_f32": [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _P],
@@ -127,9 +128,9 @@ SIGNATURES = {
 }
 EXTRA_SYMBOLS = ("hands_abi_version", "hands_error_string", "hands_conv2d_workspace_floats", "hands_pack_conv3x3_winograd_floats", "hands_conv3x3_winograd_executed_macs",
                  "hands_pack_conv3x3_winograd4_floats", "hands_conv3x3_winograd4_executed_macs",
-                 "hands_conv2d_streamk_workspace_bytes", "hands_stream_is_capturing")
+                 "hands_conv2d_streamk_workspace_bytes", "hands_stream_is_capturing", "hands_csrc_sha16", "hands_ceiling_mfma_f32")
 
-ABI_VERSION = 4      # HANDS_ABI_VERSION of include/hands_hip.h this wrapper was written against
+ABI_VERSION = 5      # HANDS_ABI_VERSION of include/hands_hip.h this wrapper was written against
 _lib = None
 
 
@@ -167,6 +168,10 @@ def lib():
     h.hands_abi_version.restype = C.c_int
     h.hands_stream_is_capturing.restype = C.c_int
     h.hands_stream_is_capturing.argtypes = [C.c_void_p]
+    h.hands_csrc_sha16.restype = C.c_char_p
+    h.hands_csrc_sha16.argtypes = []
+    h.hands_ceiling_mfma_f32.restype = C.c_longlong
+    h.hands_ceiling_mfma_f32.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p]
     h.hands_error_string.restype = C.c_char_p
     h.hands_error_string.argtypes = [C.c_int]
     _lib = h

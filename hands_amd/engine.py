@@ -184,18 +184,19 @@ class ConvEngine:
             if hook is not None:
                 hook("end", pc, B * Ho * Wo, stream, False, "conv_wino_f32_kernel")
             return Ho, Wo
-        if (self.chain_limit and not acc64 and self.math == "fp32" and (self.chain_in_kernel or self.use_splitk)
-                and pc.Kpad >= max(2 * self.chain_limit, self.chain_min_k)
+        limit = self.chain_limit if pc.sum_block < 0 else (pc.sum_block if self.chain_limit else 0)   # per-layer override of the block
+        if (limit and not acc64 and self.math == "fp32" and (self.chain_in_kernel or self.use_splitk)
+                and pc.Kpad >= max(2 * limit, self.chain_min_k)
                 and (not self.chain_max_pix or Ho * Wo <= self.chain_max_pix)
                 and not (self.chain_skip_tokens and H * W == 1 and B >= 4096)):
             # blocked summation (not the Winograd launches above: their chains are Cin long)
-            self.last_sum_block = self.chain_limit
+            self.last_sum_block = limit
             if self.chain_in_kernel:
-                if self.chain_limit not in _SUM_BLOCK:
-                    raise ValueError(f"hands_amd: chain_in_kernel takes chain_limit 64 or 128, not {self.chain_limit}")
-                d.act |= _SUM_BLOCK[self.chain_limit]
+                if limit not in _SUM_BLOCK:
+                    raise ValueError(f"hands_amd: chain_in_kernel takes chain_limit 64 or 128, not {limit}")
+                d.act |= _SUM_BLOCK[limit]
             else:
-                S = max(S, min(pc.Kpad // self.chain_limit, 32))
+                S = max(S, min(pc.Kpad // limit, 32))
         if pre is not None:
             # pointwise layer behind an eval BatchNorm -> LeakyReLU (pre = (scale, shift) device vectors): the affine +
             # activation is applied to the operand on its way into LDS (hands_conv2d_nhwc_pre_f32)

@@ -108,23 +108,26 @@ class HandOccNet(EngineSwitches, nn.Module):
         self._packed = None
         self._packed_dev = None
         self.engine = ConvEngine()
-        # Numerics of this network (DESIGN.md "Conditioning note"; round 5: tools/hon_parity_ab.py over 1000 random inputs, the fp32
-        # reference itself sits a median 2.9e-7 m / at most 6.3e-7 m from an fp64 evaluation): it amplifies ANY fp32 re-association,
-        # and what the HIP path adds on top is the length of its fp32 accumulation chains -- one k-ordered FMA chain per output in the
-        # direct kernel against ATen's blocked sums.  Two settings shorten them:
-        #   * winograd_scope = "all": every 3x3 / stride-1 layer as Winograd F(2x2,3x3), whose chains are Cin long instead of 9 Cin
-        #     (and +2-6 % throughput): 0.6 % of inputs above 1e-6 m against 1.1 % with the backbone-only scope of rounds 3-4;
-        #   * engine.chain_limit = 64, engine.chain_in_kernel: every direct launch with K >= 128 sums blocks of 64 floats (4 k-steps)
-        #     into a second accumulator set inside the kernel (HANDS_SUM_BLOCK64; no workspace, no extra launch): 0 of 1000 inputs
-        #     above 1e-6 m [Wilson 95 %: 0, 0.38 %], median 3.9e-7 / maximum 9.6e-7 m against the reference, and a median HIP-vs-fp64
-        #     error 1.02x the reference's own (maximum 5.9e-7 against the reference's 6.3e-7) -- at -2 % throughput against single chains.
-        # (Blocks of 128: 0 of 1000 as well, ratio 1.17, -0.6 %.  The split-K form of round 5's first half -- chains <= 256 on
-        #  K >= 512 -- gave 0.3 % [0.10, 0.88], ratio 1.49, -1.3 % to -4 %: profiles/r05_hon_parity_ab_1000seeds_d_summary.json.)
-        # Call invalidate_packed() after changing the scope.
+        # Numerics of this network (DESIGN.md "Conditioning note"): it amplifies ANY fp32 re-association -- the fp32 reference itself
+        # sits a median 2.9e-7 m / at most 6.3e-7 m from an fp64 evaluation and moves by 2-5e-7 m with ATen's thread count -- so the
+        # bar (1e-6 m against the reference, however it is run) needs a HIP path that is CLOSER to fp64 than the reference is.
+        # Round 6 (tools/hon_error_stages.py, tools/experiments/hon_stage_budget_cpu.py, tools/hon_parity_ab.py):
+        #   * where the error is made: the heat-map head (hand_head.py:75-94: res unit -> fc -> score -> spatial softmax) carries
+        #     ~3/4 of the reference's own excess over an exact-accumulation evaluator, the MLPs (mano_head.py:190-207, KPE) most of
+        #     the rest; the ResNet stages and the hourglass nothing.  Those two stages (2 % of the FLOPs) accumulate in fp64
+        #     (acc64_stages -> HANDS_ACC_F64: v_mfma_f64_16x16x4_f64, correctly rounded outputs), the spatial softmax runs in fp64
+        #     inside, and flash attention sums P V in 32-key blocks (its 1024-key chains were the whole FIT / SET excess);
+        #   * everything else as in round 5: winograd_scope "all" (chains Cin long instead of 9 Cin) and engine.chain_limit = 64,
+        #     chain_in_kernel (HANDS_SUM_BLOCK64) in every stage (taking the blocks out of the ResNet stages costs 0.74 -> 0.91).
+        # Result: median err(HIP, fp64) / err(reference fp32, fp64) = 0.74 (1.02 in round 5), max 3.7e-7 m against fp64 (6.9e-7),
+        # at -3 % throughput (32 samples).  An all-fp64 path reaches 0.59 at -55 %: DESIGN.md has the table.
+        # Call invalidate_packed() after changing any of these.
         self.engine.winograd = True
         self.winograd_scope = "all"        # "all" | "backbone+fit" | "backbone" (trunk + FPN smoothing) | "trunk"
         self.engine.chain_limit, self.engine.chain_min_k, self.engine.chain_in_kernel = 64, 0, True
-        self.acc64_stages = frozenset()    # stages (STAGES) whose convolutions / linear layers accumulate in fp64 (HANDS_ACC_F64)
+        self.block_stages = frozenset(STAGES)   # stages whose direct launches sum in engine.chain_limit blocks (the others: single chains)
+        self.wino_stages = None            # None: winograd_scope decides; else the stages whose 3x3 / s1 layers take Winograd F(2x2)
+        self.acc64_stages = frozenset(("reghead", "mlp"))   # stages (STAGES) whose convolutions / linear layers accumulate in fp64
         self.small_map_splitk = False  # True / "deep" / "16x16": call-site constant split-K on maps of <= 8x8 pixels and on the
                                        # one-tile 16x16 layers (see _conv_fns).  Off since round 5: with three forwards in flight the
                                        # chip is filled by other forwards, and the reduce launches cost more than the slices gain
@@ -181,15 +184,17 @@ class HandOccNet(EngineSwitches, nn.Module):
                 s, t = bn_affine(bn)
                 w, b = w * s.view(-1, 1, 1, 1), b * s + t
             sc = self.winograd_scope
-            wino = (sc == "all" or (sc == "trunk" and p.startswith("backbone.layer")) or
+            wino = stage_of(p) in self.wino_stages if self.wino_stages is not None else (sc == "all" or (sc == "trunk" and p.startswith("backbone.layer")) or
                     (sc in ("backbone", "backbone+fit") and p.startswith("backbone.")) or (sc == "backbone+fit" and p.startswith("FIT.")))
             pc = pack_conv(w, b, stride, pad, dev, cin_pad_to=cin_pad_to, winograd=wino)
             pc.acc64 = stage_of(p) in self.acc64_stages
+            pc.sum_block = -1 if stage_of(p) in self.block_stages else 0
             return pc
 
         def lin(p, **kw):
             pc = pack_linear(sd[p + ".weight"], sd[p + ".bias"], dev, **kw)
             pc.acc64 = stage_of(p) in self.acc64_stages and not p.startswith("grasp")
+            pc.sum_block = -1 if stage_of(p) in self.block_stages else 0
             return pc
 
         def preact(p):

@@ -38,6 +38,7 @@ class PackedConv:
     Kpad: int
     macs_per_pixel: int = 0   # ALGORITHMIC multiply-accumulates per output pixel (true, unpadded dims)
     wino: torch.Tensor = None  # 3x3 / stride 1 / pad 1 layers: Winograd F(2x2,3x3) weights (hands_pack_conv3x3_winograd_f64)
+    sum_block: int = -1   # blocked fp32 summation of THIS layer: -1 = the engine's chain_limit, 0 = a single chain, 64 / 128 = blocks
     acc64: bool = False   # the owning model wants this layer accumulated in fp64 (HANDS_ACC_F64; ConvEngine.conv honours it)
     wino4: torch.Tensor = None  # the same layers: Winograd F(4x4,3x3) weights (hands_pack_conv3x3_winograd4_f64), when asked for
 

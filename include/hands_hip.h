@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define HANDS_EINVAL 10001
-#define HANDS_ABI_VERSION 4
+#define HANDS_ABI_VERSION 5
 
 typedef void* hands_stream_t;
 
@@ -36,6 +36,18 @@ const char* hands_error_string(int code);
  * stream it is about to LAUNCH on (torch's "current stream" is not necessarily that stream) before it takes a path that
  * is illegal under capture: growing / zero-filling a workspace (hands_conv2d_nhwc_streamk_f32's epoch flags). */
 int hands_stream_is_capturing(hands_stream_t stream);
+/* 16 hex digits: sha256 over the kernel sources (every .hip / .h / .cpp of csrc/ and the headers of include/) THIS library was built from.  A stored
+ * counter summary (profiles/rNN_pmc_*.json) describes one binary: bench.py uses it only when the hashes agree. */
+const char* hands_csrc_sha16(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * The chip's own ceilings, measured beside the kernels they bound (csrc/ceilings.hip).  No reference
+ * counterpart.  hands_ceiling_mfma_f32: 512 workgroups x 4 waves run `iters` x 32 v_mfma_f32_32x32x2_f32 and nothing else
+ * (random_operands != 0: full-mantissa lane-dependent operands instead of constants -- the matrix pipe clocks ~7 % lower on real
+ * data); returns the FLOPs the launch executes (time it with events on `stream`), < 0 = -(error).  `out` takes 512 * 256 floats.
+ * hands_ceiling_hbm_read_f32: a streaming read of n_floats (use >= 1 GiB: beyond the 256 MB Infinity Cache), 16-byte loads. */
+long long hands_ceiling_mfma_f32(float* out, long long out_floats, int iters, int random_operands, hands_stream_t stream);
+int hands_ceiling_hbm_read_f32(const float* in, long long n_floats, float* out, hands_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution / linear layer as implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32).

@@ -1,7 +1,7 @@
 """Multi-seed parity of the SHIPPED default routes against the oracle.
 
-Winograd F(2x2,3x3) is the default 3x3 route of hands_light (every stride-1 3x3) and of handoccnet_light's backbone
-(src/models/handoccnet_light/backbone.py:44-65,68-119).  handoccnet_light amplifies any fp32 re-association, so one golden
+Winograd is the default 3x3 route of hands_light (F(4x4,3x3) in all four ResNet stages since round 5, every stride-1 3x3) and
+of handoccnet_light (F(2x2,3x3) in every 3x3 / stride-1 layer outside the fp64 stages; src/models/handoccnet_light/backbone.py:44-65,68-119).  handoccnet_light amplifies any fp32 re-association, so one golden
 seed is not evidence of the margin: here >= 8 input seeds per model run through the HIP default path and must stay within
 the north-star bar -- max vertex error <= 1e-6 m (= 1e-3 mm) and root-aligned MPJPE <= 1e-3 mm -- against the oracle, the
 two golden seeds also against the reference-generated fixtures.  The worst seed is printed and written to
@@ -63,8 +63,9 @@ def test_handoccnet_default_scope_multi_seed_parity(golden_dir):
     model = hands_amd.apply_recipe(hands_amd.HandOccNet())
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(DEV).eval()
-    assert model.engine.winograd and model.winograd_scope == "all" and model.engine.chain_limit == 64 and model.engine.chain_in_kernel, \
-        "shipped default (round 5): Winograd in every 3x3 / stride-1 layer, direct chains <= 64 floats (summed inside the launch)"
+    assert model.engine.winograd and model.winograd_scope == "all" and model.engine.chain_limit == 64 and model.engine.chain_in_kernel \
+        and model.acc64_stages == {"reghead", "mlp"} and model.engine.acc64, \
+        "shipped default (round 6): Winograd in every 3x3 / stride-1 layer, direct chains <= 64 floats, heat-map head + MLPs in fp64"
     rows, worst = _sweep(model, sd, HO.handoccnet_forward, "handoccnet_light")
     assert len(rows) >= 8
     assert worst["max_vertex_err_m"] <= BAR_M and max(r["mpjpe_mm"] for r in rows) <= BAR_MPJPE_MM, worst
@@ -80,16 +81,16 @@ def test_handoccnet_default_scope_multi_seed_parity(golden_dir):
 
 
 def test_handoccnet_error_distribution_guard():
-    """48 more input seeds (200-247) through the shipped default route (Winograd everywhere + direct chains <= 64 floats, summed
-    inside the launch).  Round 5's 1000-seed A/B (tools/hon_parity_ab.py, profiles/r05_hon_parity_ab_1000seeds_d_summary.json): 0
-    of 1000 inputs above 1e-6 m [Wilson 95 %: 0, 0.38 %], median 3.9e-7, p90 5.6e-7, maximum 9.6e-7.  Guard (the oracle here is
-    LIVE, and ATen's fp32 sums differ by 3-6e-7 m between host CPUs, so one input may land anywhere in that tail): at most ONE of
-    the 48 above 1e-6 m and none above 1.1e-6 m (round 4 tolerated three and 1.6e-6), median <= 5.5e-7, p90 <= 7.5e-7 (measured on
-    two boxes: 0 above 1e-6, median 4.3e-7, p90 6.6e-7, max 7.8e-7).
+    """48 more input seeds (200-247) through the shipped default route (round 6: Winograd everywhere + direct chains <= 64 floats +
+    the heat-map head and the MLPs accumulated in fp64 + 32-key P V blocks + fp64 spatial softmax).  The 1000-seed A/B
+    (tools/hon_parity_ab.py, profiles/r06_hon_parity_ab_1000seeds_summary.json) has 0 of 1000 inputs above 1e-6 m against the
+    reference run with 1, 8 AND 16 ATen threads.  Guard: NONE of the 48 above 1e-6 m (the oracle here is live, 8 threads, and also
+    re-run with 1 thread: the reference's own vertices move by 2-5e-7 m with the thread count, the HIP path must stay inside the
+    bar against both), median <= 5e-7, p90 <= 6.5e-7.
 
-    And the other half of the claim: the HIP path is as accurate as the reference itself.  Against an fp64 evaluation of the same
-    network on the first 12 of the seeds, the median of err(HIP, fp64) / err(fp32 oracle, fp64) is <= 1.4 (measured 1.02 over
-    1000 seeds; the fp32 oracle -- the reference's arithmetic -- is a median 2.9e-7 m from fp64 itself)."""
+    And the reason it holds: the HIP path is CLOSER to an fp64 evaluation of the network than the reference's own fp32 arithmetic.
+    Over the first 12 seeds the median of err(HIP, fp64) / err(fp32 oracle, fp64) is <= 0.95 (measured 0.74 over 1000 seeds; 1.02 in
+    round 5) and the largest err(HIP, fp64) <= 4.5e-7 m."""
     model = hands_amd.apply_recipe(hands_amd.HandOccNet())
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
@@ -97,17 +98,28 @@ def test_handoccnet_error_distribution_guard():
     ar, al = hands_amd.synthetic_mano_asset(True), hands_amd.synthetic_mano_asset(False)
     c64 = lambda d: {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}
     vstack = lambda o: torch.stack([o[f"mano.vertices.{h}"] for h in "rl"]).double().cpu()
-    errs, ratios = [], []
+    errs, errs1, ratios, e64s = [], [], [], []
+    threads = torch.get_num_threads()
     for seed in range(200, 248):
         ci, cm = synthetic_inputs(2, seed)
         ref = vstack(HO.handoccnet_forward(sd, ar, al, ci, cm))
         out = vstack(model({k: v.to(DEV) for k, v in ci.items()}, {k: v.to(DEV) for k, v in cm.items()}))
         errs.append((out - ref).abs().max().item())
+        if seed < 224:                        # the same reference arithmetic with ANOTHER blocking of ATen's sums
+            torch.set_num_threads(1)
+            try:
+                ref1 = vstack(HO.handoccnet_forward(sd, ar, al, ci, cm))
+            finally:
+                torch.set_num_threads(threads)
+            errs1.append((out - ref1).abs().max().item())
         if seed < 212:
             r64 = vstack(HO.handoccnet_forward(sd64, ar, al, c64(ci), c64(cm)))
-            ratios.append((out - r64).abs().max().item() / max((ref - r64).abs().max().item(), 1e-12))
-    e = np.sort(np.array(errs))
-    print(f"handoccnet_light, 48 seeds: median {np.median(e):.3e}, p90 {np.percentile(e, 90):.3e}, max {e[-1]:.3e}, above 1e-6: {(e > 1e-6).sum()}; "
-          f"err(HIP, fp64) / err(oracle fp32, fp64) over 12 seeds: median {np.median(ratios):.2f}, max {max(ratios):.2f}")
-    assert np.median(e) <= 5.5e-7 and np.percentile(e, 90) <= 7.5e-7 and (e > 1e-6).sum() <= 1 and e[-1] <= 1.1e-6, e[-6:]
-    assert np.median(ratios) <= 1.4, ratios
+            e64s.append((out - r64).abs().max().item())
+            ratios.append(e64s[-1] / max((ref - r64).abs().max().item(), 1e-12))
+    e, e1 = np.sort(np.array(errs)), np.sort(np.array(errs1))
+    print(f"handoccnet_light, 48 seeds vs the {threads}-thread oracle: median {np.median(e):.3e}, p90 {np.percentile(e, 90):.3e}, max {e[-1]:.3e}, "
+          f"above 1e-6: {(e > 1e-6).sum()}; 24 seeds vs the 1-thread oracle: median {np.median(e1):.3e}, max {e1[-1]:.3e}; "
+          f"err(HIP, fp64) / err(oracle fp32, fp64) over 12 seeds: median {np.median(ratios):.2f}, max {max(ratios):.2f}, max err(HIP, fp64) {max(e64s):.3e}")
+    assert (e > 1e-6).sum() == 0 and (e1 > 1e-6).sum() == 0, (e[-4:], e1[-4:])
+    assert np.median(e) <= 5e-7 and np.percentile(e, 90) <= 6.5e-7, e[-6:]
+    assert np.median(ratios) <= 0.95 and max(e64s) <= 4.5e-7, (ratios, e64s)

@@ -9,7 +9,7 @@ processes (8 threads each) created before the parent touches the GPU.
 
 usage: python tools/hon_parity_ab.py [--seeds N] [--first S] [--arms a,b,...] [--workers W] [--out gpurun_out/hon_ab.json]
        [--speed]   (hands/s of every arm at bz = 32 and 256, shipped pipelined mode)
-arm syntax: <scope>[+c...][+f:stage.stage...] (stages accumulated in fp64: resnet fpn fit set hourglass reghead encoder mlp, or ALL)
+arm syntax: <scope>[+c...][+f:stage.stage...][+b:stages][+w:stages] in THIS order (f: stages accumulated in fp64: resnet fpn fit set hourglass reghead encoder mlp, or ALL)
             <scope>[+c<chain_limit>[k<chain_min_k>][p<chain_max_pix>][t = token GEMMs unblocked][i = blocks summed inside the launch]], scope in direct | trunk | backbone | backbone+fit | all
 """
 import argparse
@@ -61,6 +61,8 @@ def wilson(k, n, z=1.96):
 
 
 def parse_arm(name):
+    name, _, wst = name.partition("+w:")           # "+w:resnet.fpn": Winograd F(2x2) in these stages only (overrides the scope)
+    name, _, blk = name.partition("+b:")           # "+b:fpn.fit.set": blocked summation in these stages only
     name, _, f64 = name.partition("+f:")           # "+f:reghead.encoder.mlp": stages accumulated in fp64
     scope, _, rest = name.partition("+c")
     limit = min_k = max_pix = 0
@@ -70,7 +72,8 @@ def parse_arm(name):
         rest, _, mp = rest.partition("p")
         lim, _, mk = rest.partition("k")
         limit, min_k, max_pix = int(lim), int(mk or 0), int(mp or 0)
-    return scope, limit, min_k, max_pix, skip_tok, in_kernel, frozenset(x for x in f64.split(".") if x)
+    fs = lambda t: frozenset(x for x in t.split(".") if x)
+    return scope, limit, min_k, max_pix, skip_tok, in_kernel, fs(f64), (fs(blk) if blk else None), (fs(wst) if wst else None)
 
 
 def main():
@@ -84,6 +87,8 @@ def main():
     ap.add_argument("--refs", default=None, help="npz from tools/hon_refs_precompute.py (first, v32, v64): no CPU forwards "
                     "here except --check of them, recomputed live and compared")
     ap.add_argument("--check", type=int, default=4)
+    ap.add_argument("--refs-threads", default="", help="more REFERENCE arms: t1=path,t16=path (npz from tools/hon_refs_threads.py: the "
+                    "fp32 oracle at another ATen thread count, same seeds); every HIP arm is compared with each")
     a = ap.parse_args()
     arms = a.arms.split(",")
     import multiprocessing as mp
@@ -107,11 +112,20 @@ def main():
     import torch
     import hands_amd
     from hands_amd.weights import synthetic_inputs
+    extra = {}                                     # reference arm name -> (first seed, v32 array)
+    for item in filter(None, a.refs_threads.split(",")):
+        nm, _, path = item.partition("=")
+        zz = np.load(path)
+        extra[nm] = (int(zz["first"]), zz["v32"])
     models = {}
     for name in arms:
-        scope, limit, min_k, max_pix, skip_tok, in_kernel, f64 = parse_arm(name)
+        scope, limit, min_k, max_pix, skip_tok, in_kernel, f64, blk, wst = parse_arm(name)
         m = hands_amd.apply_recipe(hands_amd.HandOccNet()).to("cuda").eval()
         m.acc64_stages = f64 if "ALL" not in f64 else frozenset(hands_amd.handoccnet.STAGES)
+        if blk is not None:
+            m.block_stages = blk
+        if wst is not None:
+            m.wino_stages = wst
         m.engine.winograd = scope != "direct"
         m.winograd_scope = scope if scope != "direct" else "backbone"
         m.engine.chain_limit, m.engine.chain_min_k, m.engine.chain_max_pix = limit, min_k, max_pix
@@ -119,19 +133,27 @@ def main():
         m.invalidate_packed()
         m.async_forward = False
         models[name] = m
-    res = {"arms": arms, "seeds": [], "ref32_vs_64": [], "vs32": {n: [] for n in arms}, "vs64": {n: [] for n in arms}}
+    res = {"arms": arms, "seeds": [], "ref32_vs_64": [], "vs32": {n: [] for n in arms}, "vs64": {n: [] for n in arms},
+           "vs32_other": {nm: {n: [] for n in arms} for nm in extra}, "ref_other_vs_64": {nm: [] for nm in extra},
+           "ref_other_vs_ref": {nm: [] for nm in extra}}
     t0 = time.time()
     for i, (seed, v32, v64) in enumerate(it):
         ci, cm = synthetic_inputs(2, seed)
         gi, gm = {k: v.to("cuda") for k, v in ci.items()}, {k: v.to("cuda") for k, v in cm.items()}
         res["seeds"].append(seed)
         res["ref32_vs_64"].append(float(np.abs(v32.astype(np.float64) - v64).max()))
+        others = {nm: arr[seed - f0] for nm, (f0, arr) in extra.items() if 0 <= seed - f0 < len(arr)}
+        for nm, vo in others.items():
+            res["ref_other_vs_64"][nm].append(float(np.abs(vo.astype(np.float64) - v64).max()))
+            res["ref_other_vs_ref"][nm].append(float(np.abs(vo - v32).max()))
         for name, m in models.items():
             out = m(gi, gm)
             torch.cuda.synchronize()
             v = torch.stack([out[f"mano.vertices.{h}"] for h in "rl"]).cpu().numpy()
             res["vs32"][name].append(float(np.abs(v - v32).max()))
             res["vs64"][name].append(float(np.abs(v.astype(np.float64) - v64).max()))
+            for nm, vo in others.items():
+                res["vs32_other"][nm][name].append(float(np.abs(v - vo).max()))
         if (i + 1) % 100 == 0 or i + 1 == len(seeds):
             json.dump(res, open(a.out, "w"))
             print(f"[{time.time() - t0:6.0f} s] {i + 1} seeds", flush=True)
@@ -156,6 +178,20 @@ def main():
               f"p90 {np.percentile(e, 90):.3e} p99 {np.percentile(e, 99):.3e} max {e.max():.3e} (> 1.2e-6: {(e > 1.2e-6).sum()}) | "
               f"vs fp64: median {np.median(e64):.3e} p99 {np.percentile(e64, 99):.3e} max {e64.max():.3e}, "
               f"median err(HIP,64) / err(ref32,64) = {np.median(ratio):.2f}")
+    for nm in extra:          # the reference at other thread counts: its own distance from fp64 / from the 8-thread run, and every arm against it
+        ro, rr = np.array(res["ref_other_vs_64"][nm]), np.array(res["ref_other_vs_ref"][nm])
+        summary.setdefault("refs", {})[nm] = {"n": len(ro), "vs64_median": float(np.median(ro)), "vs64_max": float(ro.max()),
+                                              "vs_ref8_median": float(np.median(rr)), "vs_ref8_max": float(rr.max())}
+        print(f"reference {nm}: {len(ro)} seeds, vs fp64 median {np.median(ro):.3e} max {ro.max():.3e}; vs the 8-thread reference median "
+              f"{np.median(rr):.3e} max {rr.max():.3e}")
+        for name in arms:
+            e = np.array(res["vs32_other"][nm][name])
+            k = int((e > 1e-6).sum())
+            lo, hi = wilson(k, len(e))
+            summary["arms"][name][f"vs_{nm}"] = {"n": len(e), "exceed": k, "wilson95": [lo, hi], "median": float(np.median(e)),
+                                                  "p99": float(np.percentile(e, 99)), "max": float(e.max())}
+            print(f"  {name:18s} vs {nm}: > 1e-6 {k:3d}/{len(e)} [{100 * lo:.2f}, {100 * hi:.2f}] %  median {np.median(e):.3e} p99 "
+                  f"{np.percentile(e, 99):.3e} max {e.max():.3e}")
     if a.speed:
         for name, m in models.items():
             m.async_forward = True
