@@ -657,10 +657,12 @@ def measure_model(ctx, workload, bz, steps, warmup, args, serial_headline=False,
         ev.record(main_stream)
         events.append(ev)
         if phase == "begin":
-            macs = pc.macs_per_pixel * npix
+            macs = getattr(pc, "group_macs", None) or pc.macs_per_pixel * npix      # a grouped launch carries its members' sums
             # algorithmic bytes: input read once + output written once (+ residual read) + weights once
             if kernel.startswith("stem_pool"):    # image in (RGB0 NHWC4, or the 3 NCHW planes), pooled 64-channel map out
                 nbytes = 4.0 * (npix * 4 * (3 if "planar" in kernel else 4) + (npix // 4) * 64 + pc.w.numel())
+            elif hasattr(pc, "group_bytes"):
+                nbytes = pc.group_bytes
             else:
                 nbytes = 4.0 * (npix * pc.Cout * (2 if has_res else 1) + npix * pc.stride * pc.stride * pc.Cin + pc.w.numel())
             # Winograd launches execute 16 / 36 of the layer's algorithmic multiplications (+ idle tile lanes): keep both counts

@@ -55,6 +55,12 @@ class EvalOut(C.Structure):
 
 # name -> argtypes; every function returns int (0 = ok) except the two noted below
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
+class ConvJob(C.Structure):
+    """hands_conv_job (include/hands_hip.h): one member of a grouped pointwise launch."""
+    _fields_ = [("desc", C.POINTER(ConvDesc)), ("in_", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p),
+                ("residual", C.c_void_p), ("out", C.c_void_p), ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p)]
+
+
 SIGNATURES = {
     "hands_conv2d_nhwc_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P],
     "hands_conv3x3_winograd_supported": [C.POINTER(ConvDesc)],
@@ -62,6 +68,8 @@ SIGNATURES = {
     "hands_conv3x3_winograd4_supported": [C.POINTER(ConvDesc)],
     "hands_conv3x3_winograd4_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
     "hands_conv2d_splitk_factor": [C.POINTER(ConvDesc)],
+    "hands_conv2d_group_class": [C.POINTER(ConvDesc), _I],
+    "hands_conv2d_group_f32": [C.POINTER(ConvJob), _I, _P],
     "hands_conv2d_nhwc_splitk_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_longlong, _P],
     "hands_conv2d_streamk_grid": [C.POINTER(ConvDesc)],
     "hands_conv2d_nhwc_streamk_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_longlong, _I, _P],

@@ -441,9 +441,15 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
       kw = tap0 - kh * a.KW;
     }
   }
+#ifdef HANDS_PRO_PRIO        // A/B variant: the same for the prologue (first loads out as early as possible), back to 0 for the k-loop
+  __builtin_amdgcn_s_setprio(HANDS_PRO_PRIO);
+#endif
   LOAD_TILES(kt0);
   STORE_TILES(0);
   __syncthreads();
+#ifdef HANDS_PRO_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 
   // fragment read offsets: row = lane&31, k half = lane>>5
   // PREC 0: chunk (2 kk + half) of row r is stored at chunk ^ ((r >> 2) & 3); the kk = 1 fragment is the kk = 0 address ^ 32 B
@@ -546,6 +552,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
     __syncthreads();
   }
   COMPUTE_STEP((kt1 - 1 - kt0) & 1);
+#ifdef HANDS_EPI_PRIO        // A/B variant (tools/build_variant.sh -DHANDS_EPI_PRIO=n): a wave in its epilogue asks for issue priority n over
+  __builtin_amdgcn_s_setprio(HANDS_EPI_PRIO);   // the k-loop waves of the other workgroups on its SIMD (it holds a slot without feeding the pipe)
+#endif
   if constexpr (BLK > 0) {                                // the last (possibly partial) block
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -693,6 +702,35 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   const int kt0 = a.ksplit > 1 ? (int)((long long)split * nk_all / a.ksplit) : 0;
   const int kt1 = a.ksplit > 1 ? (int)((long long)(split + 1) * nk_all / a.ksplit) : nk_all;
   conv_tile<WAVES_M, WAVES_N, MODE, PREC, PRE, BLK>(a, lds, tile, split, kt0, kt1, nullptr, nullptr);
+}
+
+// ---- grouped launch: up to GROUP_MAX independent pointwise layers of ONE kernel instantiation in one launch ----------------
+// handoccnet_light at 32 samples per GPU runs many small independent launches next to each other in the graph -- the q / k / v
+// (/ q2 / k2) projections of a FIT / SET block, the four FPN laterals, the two branches of an hourglass level, conv1 and the
+// downsample of a stage's first bottleneck -- each a fraction of the chip wide.  Here they are ONE grid: problem p owns the
+// blocks [start[p], start[p + 1]) (counts rounded up to the 8 XCDs so that the XCD-aware tile order of every problem is the
+// one its own launch would use); every tile runs conv_tile exactly as in the plain kernel: same bits.
+constexpr int GROUP_MAX = 8;
+struct GroupArgs {
+  ConvArgs a[GROUP_MAX];
+  int start[GROUP_MAX + 1];
+  int n;
+};
+
+template <int WAVES_M, int WAVES_N, int MODE, bool PRE, int BLK>
+__global__ void __launch_bounds__(256, 2) conv_igemm_group_f32_kernel(GroupArgs g) {
+  constexpr int RING = 2 * (64 * WAVES_M + 64 * WAVES_N) * LDS_ROW;
+  __shared__ __attribute__((aligned(16))) float lds[RING > EPI_FLOATS ? RING : EPI_FLOATS];
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < GROUP_MAX; ++i)
+    if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
+  const ConvArgs& a = g.a[p];
+  const int ntiles = a.nblk_m * a.nblk_n;
+  const int local = (int)blockIdx.x - g.start[p];
+  // the padding blocks of a problem whose tile count is not a multiple of 8: XCD x owns q + (x < r) tiles
+  if ((local >> 3) >= (ntiles >> 3) + ((local & 7) < (ntiles & 7) ? 1 : 0)) return;
+  conv_tile<WAVES_M, WAVES_N, MODE, 0, PRE, BLK>(a, lds, xcd_remap(local, ntiles), 0, 0, a.Kpad / BK, nullptr, nullptr);
 }
 
 // ---- stream-K: persistent workgroups with equal shares of (tile, k-step) units -------------------------------
@@ -958,7 +996,74 @@ bool pointwise_route_ok(const hands_conv_desc* d) {
          (long long)(d->Ho - 1) * d->stride < d->H && (long long)(d->Wo - 1) * d->stride < d->W;
 }
 
+void fill_plain_args(const hands_conv_desc* d, const float* in, const float* w_packed, const float* bias, const float* residual,
+                     float* out, const float* pre_scale, const float* pre_shift, ConvArgs& a) {
+  a.in = in; a.w = w_packed; a.bias = bias; a.res = residual; a.out = out;
+  a.M = d->B * d->Ho * d->Wo; a.N = d->Cout; a.Kpad = d->Kpad;
+  a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+  a.in_ps = d->in_pix_stride; a.out_ps = d->out_pix_stride; a.res_ps = d->res_pix_stride;
+  a.relu = d->act & HANDS_ACT_MASK;
+  a.ksplit = 1; a.partial = nullptr; a.part_ps = 0; a.pre_scale = pre_scale; a.pre_shift = pre_shift;
+  a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
+  a.nblk_m = a.nblk_n = 0;
+}
+
+// The kernel instantiation a POINTWISE layer runs (the unit a grouped launch is homogeneous in), or -1 when the layer cannot
+// be grouped: bit 0 narrow tile (256 x 64), bit 1 blocked summation (64 floats), bit 2 operand affine + LeakyReLU.
+int group_class(const hands_conv_desc* d, bool pre) {
+  if (!d || !conv_geometry_ok(d) || !pointwise_route_ok(d)) return -1;
+  if (d->act & (HANDS_MATH_BF16X3 | HANDS_SUM_BLOCK128 | HANDS_ACC_F64)) return -1;
+  return (d->Cout <= 64 ? 1 : 0) | ((d->act & HANDS_SUM_BLOCK64) ? 2 : 0) | (pre ? 4 : 0);
+}
+
+template <int WAVES_M, int WAVES_N, bool PRE, int BLK>
+int launch_group(GroupArgs& g, hipStream_t stream) {
+  constexpr int BM = 64 * WAVES_M, BN = 64 * WAVES_N;
+  long long total = 0;
+  for (int p = 0; p < g.n; ++p) {
+    ConvArgs& a = g.a[p];
+    a.nblk_m = (a.M + BM - 1) / BM;
+    a.nblk_n = (a.N + BN - 1) / BN;
+    g.start[p] = (int)total;
+    total += ((long long)a.nblk_m * a.nblk_n + 7) / 8 * 8;
+    if (total > 0x7fffffffLL) return HANDS_EINVAL;
+  }
+  for (int p = g.n; p <= GROUP_MAX; ++p) g.start[p] = (int)total;
+  hipLaunchKernelGGL((conv_igemm_group_f32_kernel<WAVES_M, WAVES_N, 2, PRE, BLK>), dim3((unsigned)total), dim3(256), 0, stream, g);
+  return (int)hipGetLastError();
+}
+
 }  // namespace
+
+extern "C" int hands_conv2d_group_class(const hands_conv_desc* d, int pre) { return group_class(d, pre != 0); }
+
+extern "C" int hands_conv2d_group_f32(const hands_conv_job* jobs, int n, hands_stream_t stream) {
+  if (!jobs || n < 1 || n > GROUP_MAX) return HANDS_EINVAL;
+  GroupArgs g;
+  g.n = n;
+  int cls = -2;
+  for (int p = 0; p < n; ++p) {
+    const hands_conv_job& j = jobs[p];
+    if (!j.desc || !j.in || !j.w_packed || !j.bias || !j.out || ((j.pre_scale != nullptr) != (j.pre_shift != nullptr))) return HANDS_EINVAL;
+    const int c = group_class(j.desc, j.pre_scale != nullptr);
+    if (c < 0 || (cls != -2 && c != cls)) return HANDS_EINVAL;        // one instantiation per launch
+    cls = c;
+    fill_plain_args(j.desc, j.in, j.w_packed, j.bias, j.residual, j.out, j.pre_scale, j.pre_shift, g.a[p]);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  switch (cls) {
+    case 0: return launch_group<2, 2, false, 0>(g, s);
+    case 1: return launch_group<4, 1, false, 0>(g, s);
+    case 2: return launch_group<2, 2, false, 4>(g, s);
+    case 3: return launch_group<4, 1, false, 4>(g, s);
+    case 4: return launch_group<2, 2, true, 0>(g, s);
+    case 5: return launch_group<4, 1, true, 0>(g, s);
+    case 6: return launch_group<2, 2, true, 4>(g, s);
+    case 7: return launch_group<4, 1, true, 4>(g, s);
+  }
+  return HANDS_EINVAL;
+}
 
 extern "C" int hands_conv2d_splitk_factor(const hands_conv_desc* d) { return d ? splitk_factor(d) : 0; }
 

@@ -13,7 +13,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import ConvDesc, check, ptr
+from ._lib import ConvDesc, ConvJob, check, ptr
 
 MATH_BF16X3 = 0x100   # HANDS_MATH_BF16X3 (include/hands_hip.h)
 _SUM_BLOCK = {128: 0x200, 64: 0x400}   # HANDS_SUM_BLOCK128 / HANDS_SUM_BLOCK64
@@ -63,6 +63,8 @@ class ConvEngine:
                                       # v_mfma_f64_16x16x4_f64, correctly rounded fp32 outputs, half the fp32 matrix rate) -- ONE plain
                                       # direct launch, never Winograd / split-K / stream-K / blocked.  HandOccNet marks its heat-map head,
                                       # encoder and MLPs (DESIGN.md "Conditioning note"); False = those layers take the fp32 routes
+        self.group_launches = True    # conv_group(): independent pointwise layers of one kernel instantiation as ONE launch
+                                      # (hands_conv2d_group_f32, bit-identical to the separate launches); False = one launch each
         self.last_acc64 = False       # the launch the hook is being called for accumulates in fp64
         self.hook = None              # callable(phase, pc, npix, stream_handle, has_res, kernel): bench.py brackets
                                       # every MFMA launch (conv_igemm and the fused stem) with events; `kernel` is the
@@ -81,7 +83,7 @@ class ConvEngine:
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
         for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "winograd", "winograd4", "fuse_mano", "fuse_pre", "stream_k", "math", "chain_limit",
-                  "chain_min_k", "chain_max_pix", "chain_skip_tokens", "chain_in_kernel", "acc64"):
+                  "chain_min_k", "chain_max_pix", "chain_skip_tokens", "chain_in_kernel", "acc64", "group_launches"):
             setattr(e, k, getattr(self, k))
         return e
 
@@ -240,6 +242,69 @@ class ConvEngine:
             hook("end", pc, B * Ho * Wo, stream, res is not None, kname)
         return Ho, Wo
 
+    def conv_group(self, L, jobs, stream):
+        """Independent layers that may run concurrently: ``jobs`` is a list of dicts with the arguments of :meth:`conv` (``pc, x, B,
+        H, W, out, relu`` + optional ``res, pre, in_ps, out_ps, res_ps, x_off, out_off, res_off``).  Pointwise jobs that select the
+        same kernel instantiation (hands_conv2d_group_class) go out as ONE launch of up to 8 (hands_conv2d_group_f32: every tile is
+        computed exactly as its own launch would, same bits); everything else -- 3x3 layers, fp64 or split-K layers, a class with a
+        single member -- takes :meth:`conv`.  The outputs must not alias each other or any input of the group."""
+        single = lambda j: self.conv(L, j["pc"], j["x"], j["B"], j["H"], j["W"], j["out"], j.get("relu", 0), stream,
+                                     **{k: j[k] for k in ("res", "pre", "in_ps", "out_ps", "res_ps", "x_off", "out_off", "res_off") if k in j})
+        if len(jobs) < 2 or not self.group_launches or self.latency_mode or self.math != "fp32":
+            for j in jobs:
+                single(j)
+            return
+        classes = {}
+        for j in jobs:
+            pc, B, H, W = j["pc"], j["B"], j["H"], j["W"]
+            res, pre = j.get("res"), j.get("pre")
+            Ho = (H + 2 * pc.pad - pc.KH) // pc.stride + 1
+            Wo = (W + 2 * pc.pad - pc.KW) // pc.stride + 1
+            d = ConvDesc(B, H, W, pc.Cin, Ho, Wo, pc.Cout, pc.KH, pc.KW, pc.stride, pc.pad, j.get("in_ps") or pc.Cin,
+                         j.get("out_ps") or pc.Cout, (pc.Cout if j.get("res_ps") is None else j["res_ps"]) if res is not None else 0,
+                         pc.Kpad, int(j.get("relu", 0)))
+            cls = -1
+            if not (self.acc64 and pc.acc64 and pc.Cin != 4):
+                limit = self.chain_limit if pc.sum_block < 0 else (pc.sum_block if self.chain_limit else 0)
+                blocked = bool(limit and self.chain_in_kernel and pc.Kpad >= max(2 * limit, self.chain_min_k)
+                               and (not self.chain_max_pix or Ho * Wo <= self.chain_max_pix)
+                               and not (self.chain_skip_tokens and H * W == 1 and B >= 4096))
+                if limit and not self.chain_in_kernel:
+                    blocked = None                     # the split-K form of the blocks: not a grouped launch
+                if blocked is not None:
+                    if blocked:
+                        if limit not in _SUM_BLOCK:
+                            raise ValueError(f"hands_amd: chain_in_kernel takes chain_limit 64 or 128, not {limit}")
+                        d.act |= _SUM_BLOCK[limit]
+                    cls = L.hands_conv2d_group_class(C.byref(d), 1 if pre is not None else 0)
+                    j["_blocked"] = limit if blocked else 0
+            j["_d"], j["_npix"] = d, B * Ho * Wo
+            classes.setdefault(cls, []).append(j)
+        hook = self.hook
+        for cls, members in classes.items():
+            if cls < 0 or len(members) < 2:
+                for j in members:
+                    single(j)
+                continue
+            for i in range(0, len(members), 8):
+                chunk = members[i:i + 8]
+                if len(chunk) == 1:
+                    single(chunk[0])
+                    continue
+                arr = (ConvJob * len(chunk))()
+                for k, j in enumerate(chunk):
+                    pc, res, pre = j["pc"], j.get("res"), j.get("pre")
+                    arr[k] = ConvJob(C.pointer(j["_d"]), ptr(j["x"], j.get("x_off", 0)), ptr(pc.w), ptr(pc.bias),
+                                     ptr(res, j.get("res_off", 0)) if res is not None else None, ptr(j["out"], j.get("out_off", 0)),
+                                     ptr(pre[0]) if pre is not None else None, ptr(pre[1]) if pre is not None else None)
+                self.last_sum_block, self.last_acc64 = chunk[0]["_blocked"], False
+                if hook is not None:
+                    gp = _GroupPC(chunk)
+                    hook("begin", gp, gp.npix, stream, any(j.get("res") is not None for j in chunk), "conv_igemm_group_f32_kernel")
+                check(L.hands_conv2d_group_f32(arr, len(chunk), stream), "hands_conv2d_group_f32")
+                if hook is not None:
+                    hook("end", gp, gp.npix, stream, False, "conv_igemm_group_f32_kernel")
+
     def conv_dual(self, L, pc, split, x, x2, B, Ho, Wo, H2, W2, out, stream, act=1, out_off=0):
         """act(conv3(x) + downsample(x2)) (resnet.py:146-154) with the identity never materialised."""
         K0, K1, stride2 = split
@@ -278,6 +343,21 @@ class ConvEngine:
         if hook is not None:
             hook("end", pc, B * Hc * Wc, stream, False, "stem_pool_planar_kernel")
         return Hc, Wc
+
+
+class _GroupPC:
+    """What the profiling hook sees for a grouped launch: the summed work of its members (bench.py prices a launch from
+    ``group_macs`` / ``group_bytes`` when they exist)."""
+
+    def __init__(self, chunk):
+        self.npix = sum(j["_npix"] for j in chunk)
+        self.group_macs = sum(j["pc"].macs_per_pixel * j["_npix"] for j in chunk)
+        self.group_bytes = sum(4.0 * (j["_npix"] * j["pc"].Cout * (2 if j.get("res") is not None else 1)
+                                      + j["_npix"] * j["pc"].stride ** 2 * j["pc"].Cin + j["pc"].w.numel()) for j in chunk)
+        pc0 = chunk[0]["pc"]
+        self.Cin, self.Cout, self.KH, self.stride, self.w = pc0.Cin, pc0.Cout, 1, pc0.stride, pc0.w
+        self.macs_per_pixel = self.group_macs / max(self.npix, 1)
+        self.members = len(chunk)
 
 
 DEFAULT_ENGINE = ConvEngine()

@@ -352,6 +352,27 @@ class HandOccNet(EngineSwitches, nn.Module):
             independent, so the 2*bz crops may be cut into chunks that run on separate HIP streams."""
             npix = B2 * NTOK
             conv, hconv = _conv_fns(L, stream, new, self.engine, self.small_map_splitk)
+
+            def group(*jobs):
+                """Independent layers (pc, x, B, H, W[, act[, res[, pre]]]) -> their outputs; pointwise ones of one kernel class
+                leave as ONE launch (ConvEngine.conv_group), the rest as their own."""
+                if self.small_map_splitk:                      # the call-site split-K rules live in conv()
+                    return [conv(j[0], j[1], j[2], j[3], j[4], *(j[5:6] or (ACT_NONE,)), res=(j[6] if len(j) > 6 else None),
+                                 **({"pre": j[7]} if len(j) > 7 and j[7] is not None else {}))[0] for j in jobs]
+                js = []
+                for j in jobs:
+                    pc, x, B_, H_, W_ = j[:5]
+                    Ho = (H_ + 2 * pc.pad - pc.KH) // pc.stride + 1
+                    Wo = (W_ + 2 * pc.pad - pc.KW) // pc.stride + 1
+                    d = {"pc": pc, "x": x, "B": B_, "H": H_, "W": W_, "out": new(B_, Ho, Wo, pc.Cout), "relu": j[5] if len(j) > 5 else ACT_NONE}
+                    if len(j) > 6 and j[6] is not None:
+                        d["res"] = j[6]
+                    if len(j) > 7 and j[7] is not None:
+                        d["pre"] = j[7]
+                    js.append(d)
+                self.engine.conv_group(L, js, stream)
+                return [d["out"] for d in js]
+
             if self.pos_enc is not None:
                 enc = new(B2, P["kpe0"].Cin)
                 check(L.hands_kpe_encode_f32(ptr(center), ptr(corner), ptr(enc), B2, P["kpe0"].Cin, self.n_freq, stream), "kpe")
@@ -374,9 +395,11 @@ class HandOccNet(EngineSwitches, nn.Module):
             stages = []
             for blocks in P["layers"]:
                 for e in blocks:
-                    t1, _, _ = conv(e["c1"], cur, B2, H, W, ACT_LEAKY_RELU)
+                    if "ds" in e:        # conv1 and the downsample branch read the same map: one launch where their tiles agree
+                        t1, ident = group((e["c1"], cur, B2, H, W, ACT_LEAKY_RELU), (e["ds"], cur, B2, H, W))
+                    else:
+                        t1, ident = conv(e["c1"], cur, B2, H, W, ACT_LEAKY_RELU)[0], cur
                     t2, H2, W2 = conv(e["c2"], t1, B2, H, W, ACT_LEAKY_RELU)
-                    ident = conv(e["ds"], cur, B2, H, W)[0] if "ds" in e else cur
                     cur, _, _ = conv(e["c3"], t2, B2, H2, W2, ACT_LEAKY_RELU, res=ident)
                     H, W = H2, W2
                 stages.append((cur, H, W))
@@ -386,10 +409,12 @@ class HandOccNet(EngineSwitches, nn.Module):
                 out = new(B2, Hh, Ww, CF)
                 check(L.hands_upsample_bilinear_add_f32(ptr(x), ptr(y), ptr(out), B2, h, w, Hh, Ww, CF, stream), "up_add")
                 return out
-            p5, _, _ = conv(P["toplayer"], c5, B2, h5, w5)
-            p4 = up_add(p5, h5, w5, conv(P["latlayer1"], c4, B2, h4, w4)[0], h4, w4)
-            p3 = up_add(p4, h4, w4, conv(P["latlayer2"], c3, B2, h3, w3)[0], h3, w3)
-            p2 = up_add(p3, h3, w3, conv(P["latlayer3"], c2, B2, h2, w2)[0], h2, w2)
+            # the top layer and the three laterals are independent of the top-down chain: one launch
+            p5, l4, l3, l2 = group((P["toplayer"], c5, B2, h5, w5), (P["latlayer1"], c4, B2, h4, w4),
+                                   (P["latlayer2"], c3, B2, h3, w3), (P["latlayer3"], c2, B2, h2, w2))
+            p4 = up_add(p5, h5, w5, l4, h4, w4)
+            p3 = up_add(p4, h4, w4, l3, h3, w3)
+            p2 = up_add(p3, h3, w3, l2, h2, w2)
             p2, _, _ = conv(P["smooth3"], p2, B2, h2, w2)          # smooth2(p3) of the reference is dead code
             Hf, Wf = h2 // 2, w2 // 2
             assert Hf * Wf == NTOK
@@ -410,13 +435,14 @@ class HandOccNet(EngineSwitches, nn.Module):
                 qe, ke = new(npix, CF), new(npix, CF)
                 check(L.hands_add_embed2_f32(ptr(query), ptr(key), ptr(e["qemb"]), ptr(e["kemb"]), ptr(kpe), ptr(qe), ptr(ke),
                                              B2, NTOK, CF, stream), "add_embed")
-                v = conv(e["v"], key, npix, 1, 1)[0]
-                q = conv(e["q"], qe, npix, 1, 1)[0]
-                k = conv(e["k"], ke, npix, 1, 1)[0]
+                # the three (five) projections of a block: one launch
+                if injection:
+                    v, q, k, q2, k2 = group((e["v"], key, npix, 1, 1), (e["q"], qe, npix, 1, 1), (e["k"], ke, npix, 1, 1),
+                                            (e["q2"], qe, npix, 1, 1), (e["k2"], ke, npix, 1, 1))
+                else:
+                    v, q, k = group((e["v"], key, npix, 1, 1), (e["q"], qe, npix, 1, 1), (e["k"], ke, npix, 1, 1))
                 x = new(npix, CF)
                 if injection:
-                    q2 = conv(e["q2"], qe, npix, 1, 1)[0]
-                    k2 = conv(e["k2"], ke, npix, 1, 1)[0]
                     k2sum = new(B2, CF)
                     check(L.hands_token_sum_f32(ptr(k2), ptr(k2sum), B2, NTOK, CF, stream), "token_sum")
                     check(L.hands_flash_attention_f32(ptr(q), ptr(k), ptr(v), ptr(q2), ptr(k2sum), None, ptr(x), B2, NTOK,
@@ -465,10 +491,20 @@ class HandOccNet(EngineSwitches, nn.Module):
                 check(L.hands_pool2x2_nhwc_f32(ptr(x), ptr(o), B2, H, W, CF, mode, stream), "pool2x2")
                 return o
 
+            def unit2(ua, xa, Ha, Wa, ub, xb, Hb, Wb):
+                """Two independent pre-activation units (the up and low branches of an hourglass level): their conv1 pair and their
+                conv3 pair as one launch each, the 3x3 layers on their own."""
+                if not (self.engine.fuse_pre and self.engine.math == "fp32"):
+                    return unit(ua, xa, Ha, Wa), unit(ub, xb, Hb, Wb)
+                t1a, t1b = group((ua["c1"], xa, B2, Ha, Wa, ACT_LEAKY_RELU, None, ua["pre"]),
+                                 (ub["c1"], xb, B2, Hb, Wb, ACT_LEAKY_RELU, None, ub["pre"]))
+                t2a = conv(ua["c2"], t1a, B2, Ha, Wa, ACT_LEAKY_RELU)[0]
+                t2b = conv(ub["c2"], t1b, B2, Hb, Wb, ACT_LEAKY_RELU)[0]
+                return group((ua["c3"], t2a, B2, Ha, Wa, ACT_NONE, xa), (ub["c3"], t2b, B2, Hb, Wb, ACT_NONE, xb))
+
             def hourglass(n, x, H, W):                                  # hand_head.py:217-235
                 lv = P["hg"][n - 1]
-                up1 = unit(lv[0], x, H, W)
-                low1 = unit(lv[1], pool(x, H, W, 1), H // 2, W // 2)
+                up1, low1 = unit2(lv[0], x, H, W, lv[1], pool(x, H, W, 1), H // 2, W // 2)
                 low2 = hourglass(n - 1, low1, H // 2, W // 2) if n > 1 else unit(lv[3], low1, H // 2, W // 2)
                 low3 = unit(lv[2], low2, H // 2, W // 2)
                 o = new(B2, H, W, CF)

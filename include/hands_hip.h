@@ -112,6 +112,26 @@ int hands_conv2d_nhwc_f32(const hands_conv_desc* d, const float* in, const float
                           const float* bias, const float* residual, float* out,
                           hands_stream_t stream);
 
+/* Grouped launch (round 6): up to 8 INDEPENDENT pointwise layers (1x1, no padding, any stride) in ONE launch -- the q / k / v
+ * projections of an attention block (handoccnet_light/transformer.py:117-135), the FPN laterals (backbone.py:54-57), the two
+ * branches of an hourglass level (hand_head.py:217-235), conv1 + downsample of a stage's first bottleneck (resnet.py:134-154).
+ * Every job computes exactly what hands_conv2d_nhwc_f32 (pre_scale == NULL) / hands_conv2d_nhwc_pre_f32 (S = 1) would, bit for
+ * bit; all jobs of a launch must run the same kernel instantiation: hands_conv2d_group_class(desc, pre) >= 0 and equal for all
+ * (-1: not a pointwise layer, or a flag the grouped kernel has no form for -- bf16x3, 128-float blocks, fp64 accumulation),
+ * otherwise HANDS_EINVAL and nothing is launched.  The outputs of a launch must not overlap each other or any input of it. */
+typedef struct hands_conv_job {
+  const hands_conv_desc* desc;
+  const float* in;
+  const float* w_packed;
+  const float* bias;
+  const float* residual;      /* or NULL */
+  float* out;
+  const float* pre_scale;     /* both NULL, or the operand affine of hands_conv2d_nhwc_pre_f32 */
+  const float* pre_shift;
+} hands_conv_job;
+int hands_conv2d_group_class(const hands_conv_desc* d, int pre);
+int hands_conv2d_group_f32(const hands_conv_job* jobs, int n, hands_stream_t stream);
+
 /* 3x3 / stride 1 / pad 1 convolution (+ folded BatchNorm bias + activation) as Winograd F(2x2, 3x3) on the fp32 matrix
  * cores (csrc/conv_wino.hip): 16 instead of 36 multiplications per 2x2 output pixels and (cin, cout) pair.  Same layer
  * semantics as hands_conv2d_nhwc_f32 with desc.KH = KW = 3, stride 1, pad 1 and no residual

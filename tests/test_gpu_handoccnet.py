@@ -341,3 +341,86 @@ def test_graphed_handoccnet_is_bit_identical(hon_gpu, bz):
         g2(*bad)
     with pytest.raises(ValueError):         # persistent-workspace models cannot have two captured instances in flight
         GraphedForward(hands_amd.HandsLight(), *samples[0], depth=2)
+
+
+def test_grouped_pointwise_launch_is_bit_identical_to_separate_launches():
+    """hands_conv2d_group_f32 (ConvEngine.conv_group): independent pointwise layers of one kernel instantiation as ONE launch --
+    different M, K, strides, activations, a residual, partial tiles, tile counts that are not multiples of 8 -- equal their own
+    launches bit for bit; a member of another class (narrow tile, 3x3, fp64) silently takes its own launch; the C entry refuses a
+    mixed group (HANDS_EINVAL, nothing launched)."""
+    import ctypes as C
+    from hands_amd.engine import ConvEngine
+    from hands_amd.packing import pack_conv
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    mk = lambda Cout, Cin, k=1, stride=1: pack_conv(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5,
+                                                    torch.randn(Cout, generator=g), stride, k // 2, DEV)
+    xs = {256: torch.randn(5, 16, 16, 256, generator=g).to(DEV), 512: torch.randn(3, 9, 7, 512, generator=g).to(DEV),
+          64: torch.randn(70, 1, 1, 64, generator=g).to(DEV)}
+    res = torch.randn(5, 16, 16, 256, generator=g).to(DEV)
+    pre = ((torch.rand(256, generator=g) + 0.5).to(DEV), (0.1 * torch.randn(256, generator=g)).to(DEV))
+    specs = [  # pc, x key, B, H, W, act, res, pre
+        (mk(256, 256), 256, 5, 16, 16, 3, res, None), (mk(128, 256), 256, 5, 16, 16, 0, None, None),
+        (mk(512, 256, 1, 2), 256, 5, 16, 16, 1, None, None), (mk(72, 512), 512, 3, 9, 7, 3, None, None),
+        (mk(256, 64), 64, 70, 1, 1, 2, None, None),
+        (mk(64, 256), 256, 5, 16, 16, 1, None, None),          # narrow tile: another class
+        (mk(128, 256, 3), 256, 5, 16, 16, 1, None, None),      # 3x3: not a pointwise layer
+        (mk(128, 256), 256, 5, 16, 16, 3, None, pre), (mk(256, 256), 256, 5, 16, 16, 3, None, pre),     # the PRE class: a group of its own
+    ]
+
+    def run(grouped, chain):
+        eng = ConvEngine()
+        eng.winograd = False
+        eng.group_launches = grouped
+        if chain:
+            eng.chain_limit, eng.chain_in_kernel = 64, True
+        kernels = []
+        eng.hook = lambda phase, pc_, npix, st, has_res, kernel: kernels.append((kernel, getattr(pc_, "members", 1))) if phase == "begin" else None
+        jobs = []
+        for pc, xk, B, H, W, act, r, p in specs:
+            Ho, Wo = (H + 2 * pc.pad - pc.KH) // pc.stride + 1, (W + 2 * pc.pad - pc.KW) // pc.stride + 1
+            j = {"pc": pc, "x": xs[xk], "B": B, "H": H, "W": W, "relu": act, "out": torch.full((B, Ho, Wo, pc.Cout), float("nan"), device=DEV)}
+            if r is not None:
+                j["res"] = r
+            if p is not None:
+                j["pre"] = p
+            jobs.append(j)
+        eng.conv_group(L, jobs, _stream())
+        torch.cuda.synchronize()
+        return [j["out"] for j in jobs], kernels
+
+    for chain in (False, True):
+        a, ka = run(False, chain)
+        b, kb = run(True, chain)
+        assert all(k == ("conv_igemm_f32_kernel", 1) for k in ka) and len(ka) == len(specs)
+        groups = sorted(m for k, m in kb if k == "conv_igemm_group_f32_kernel")
+        # without blocks: the five wide plain layers together + the two PRE layers; with 64-float blocks the K = 64 layer keeps a
+        # single chain (another class) and leaves the plain group
+        assert groups == ([2, 4] if chain else [2, 5]), kb
+        for i, (ta, tb) in enumerate(zip(a, b)):
+            assert torch.isfinite(tb).all() and torch.equal(ta, tb), i
+    # the C entry itself: mixed classes are refused before anything is launched
+    d0 = _lib.ConvDesc(5, 16, 16, 256, 16, 16, 256, 1, 1, 1, 0, 256, 256, 0, 256, 0)
+    d1 = _lib.ConvDesc(5, 16, 16, 256, 16, 16, 64, 1, 1, 1, 0, 256, 64, 0, 256, 0)
+    assert L.hands_conv2d_group_class(C.byref(d0), 0) == 0 and L.hands_conv2d_group_class(C.byref(d1), 0) == 1
+    out = torch.full((5, 16, 16, 256), float("nan"), device=DEV)
+    arr = (_lib.ConvJob * 2)(_lib.ConvJob(C.pointer(d0), ptr(xs[256]), ptr(specs[0][0].w), ptr(specs[0][0].bias), None, ptr(out), None, None),
+                             _lib.ConvJob(C.pointer(d1), ptr(xs[256]), ptr(specs[5][0].w), ptr(specs[5][0].bias), None, ptr(out), None, None))
+    assert L.hands_conv2d_group_f32(arr, 2, _stream()) == 10001
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all()
+
+
+def test_handoccnet_forward_is_bit_identical_without_grouped_launches(hon_gpu):
+    """The grouped launches of the forward (conv1 + downsample, the FPN laterals, the q / k / v projections, the hourglass branch
+    pairs) are a launch schedule: every output equals the one-launch-per-layer forward bit for bit, at 3 and at 32 samples."""
+    for bz in (3, 32):
+        inputs, meta_info = synthetic_inputs(bz, 8, device=DEV)
+        a = {k: v.clone() for k, v in hon_gpu(inputs, meta_info).items()}
+        hon_gpu.engine.group_launches = False
+        try:
+            b = {k: v.clone() for k, v in hon_gpu(inputs, meta_info).items()}
+        finally:
+            hon_gpu.engine.group_launches = True
+        for k in a:
+            assert torch.equal(a[k], b[k]), (bz, k)

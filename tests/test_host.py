@@ -156,7 +156,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()                                   # loads without a GPU
     for name in declared:
         assert hasattr(L, name), name
-    assert L.hands_abi_version() == _lib.ABI_VERSION == 4
+    assert L.hands_abi_version() == _lib.ABI_VERSION == 5
     assert L.hands_error_string(0) == b"ok" and b"invalid" in L.hands_error_string(10001)
     assert ctypes.sizeof(_lib.ConvDesc) == 16 * 4
 

@@ -16,6 +16,8 @@ else
 fi
 if [ -n "$REPL" ]; then cp $REPL $D/${4:-conv_igemm.hip}; fi
 cd $D
+# the source hash the library reports (hands_csrc_sha16): this variant's own sources + flags, never the tree's
+printf '#define HANDS_CSRC_SHA16 "%s"\n' "$( (cat $(ls *.hip *.h *.cpp | sort); echo "$EXTRA_FLAGS") | sha256sum | cut -c1-16)" > csrc_sha.inc
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I. -fno-fast-math -ffp-contract=off -Wno-unused-function $EXTRA_FLAGS"   # EXTRA_FLAGS: e.g. -DHANDS_EPI_SCALAR_ADDS
 OBJS=""
 for f in *.hip; do X=""; if [ "$f" = "conv_wino.hip" ]; then X="-fno-slp-vectorize"; fi; /opt/rocm/bin/hipcc $FLAGS $X -c $f -o ${f%.hip}.o & OBJS="$OBJS ${f%.hip}.o"; done
