@@ -260,7 +260,7 @@ def pmc_child(args):
     model = hands_amd.apply_recipe(ctor()).to("cuda").eval()
     model.overlap_trunks = False
     inputs, meta = hands_amd.synthetic_inputs(args.bz or default_bz(wl, 1), seed=0, device="cuda")
-    for _ in range(2):
+    for _ in range(int(os.environ.get("HANDS_PMC_CHILD_FORWARDS", "2"))):     # (tools/launches_per_forward.sh diffs two counts)
         dict(model(inputs, meta).items())
         torch.cuda.synchronize()
 

@@ -71,6 +71,7 @@ SIGNATURES = {
     "hands_conv2d_group_class": [C.POINTER(ConvDesc), _I],
     "hands_conv2d_group_f32": [C.POINTER(ConvJob), _I, _P],
     "hands_conv2d_nhwc_splitk_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_longlong, _P],
+    "hands_conv2d_nhwc_splitk_fused_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P, C.c_longlong, _P, C.c_longlong, _P],
     "hands_conv2d_streamk_grid": [C.POINTER(ConvDesc)],
     "hands_conv2d_nhwc_streamk_f32": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_longlong, _I, _P],
     "hands_conv1x1_dual_nhwc_f32": [C.POINTER(ConvDesc), _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],

@@ -96,6 +96,12 @@ struct ConvArgs {
   // (handoccnet_light/hand_head.py:131-133,170-172), applied on the way into LDS instead of by a launch of its own
   const float* pre_scale;
   const float* pre_shift;
+  // fused split-K reduction (round 6): per-tile arrival counters (zero before the launch, left zero by it).  The LAST slice of a
+  // tile to arrive adds the partial sums in ascending slice order and runs the epilogue -- no second launch; nullptr = the
+  // reduce kernel does it.  fin_res / fin_act: the epilogue's residual and activation (a.res / a.relu are off in split-K slices)
+  int* counters = nullptr;
+  const float* fin_res = nullptr;
+  int fin_act = 0;
 };
 
 // XCD-aware block remap: blocks are dispatched round-robin over the 8 XCDs (private L2 each);
@@ -170,6 +176,65 @@ __device__ __forceinline__ void epilogue_full(const f32x16 (&acc)[2][2], float* 
       // rows in pairs: without the fence the scheduler hoists all eight LDS reads (+32 live registers on top of
       // the 64 accumulators and 32 residual values: 160+ VGPRs, 3 waves per SIMD instead of 4)
       if (r & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// Split-K without the second launch: called by every slice of a tile after its partial sums are stored.  The slice that arrives
+// last (agent-scope counter; release before the count, acquire after it -- the stream-K hand-off's protocol) reduces the tile:
+// partial sums in ASCENDING slice order whoever arrives last, then bias, residual, activation -- operation for operation what
+// splitk_reduce_kernel / splitk_reduce_f64_kernel do, so the output bits are those of the two-launch form.
+template <int BM, int BN, bool F64>
+__device__ __forceinline__ void splitk_fused_tail(const ConvArgs& a, int tile, int m0, int n0) {
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's partial stores have left
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int old = __hip_atomic_fetch_add(a.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == a.ksplit - 1;
+    if (last) __hip_atomic_store(a.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const int tid = threadIdx.x;
+  const size_t slice = (size_t)a.M * a.part_ps;
+  if constexpr (F64) {
+    const double* part = reinterpret_cast<const double*>(a.partial);
+    for (int idx = tid; idx < BM * BN; idx += 256) {
+      const int m = m0 + idx / BN, n = n0 + idx % BN;
+      if (m >= a.M || n >= a.N) continue;
+      const double* p = part + (size_t)m * a.part_ps + n;
+      double v = p[0];
+      for (int sl = 1; sl < a.ksplit; ++sl) v += p[sl * slice];
+      float f = (float)(v + (double)a.bias[n]);
+      if (a.fin_res) f += a.fin_res[(size_t)m * a.res_ps + n];
+      if (a.fin_act == HANDS_ACT_RELU) f = fmaxf(f, 0.f);
+      else if (a.fin_act == HANDS_ACT_GELU) f = gelu_erf(f);
+      else if (a.fin_act == HANDS_ACT_LEAKY_RELU) f = f > 0.f ? f : 0.01f * f;
+      a.out[(size_t)m * a.out_ps + n] = f;
+    }
+  } else {
+    constexpr int C4 = BN / 4;
+    for (int idx = tid; idx < BM * C4; idx += 256) {
+      const int m = m0 + idx / C4, n = n0 + (idx % C4) * 4;
+      if (m >= a.M || n >= a.N) continue;
+      const float* p = a.partial + (size_t)m * a.part_ps + n;
+      float4 v = *reinterpret_cast<const float4*>(p);
+      for (int sl = 1; sl < a.ksplit; ++sl) {
+        const float4 q = *reinterpret_cast<const float4*>(p + sl * slice);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      if (a.fin_res) {
+        const float4 r = *reinterpret_cast<const float4*>(a.fin_res + (size_t)m * a.res_ps + n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ps + n) = apply_act(v, a.fin_act);
     }
   }
 }
@@ -639,6 +704,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
             const int m = m0 + wm * 64 + 16 * jb + (lane & 15);
             if (m < a.M && ch < a.N) pd[(size_t)m * a.part_ps + ch] = accd[i][jb][r];
           }
+      if (a.counters != nullptr) splitk_fused_tail<BM, BN, true>(a, tile, m0, n0);
       return;
     }
   }
@@ -685,6 +751,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
       v = apply_act(v, act);
       if (m < a.M && n_ok) *reinterpret_cast<float4*>(obase + (size_t)m * ops + n_lane) = v;
     }
+  }
+  if constexpr (!F64) {
+    if (part && a.counters != nullptr) splitk_fused_tail<BM, BN, false>(a, tile, m0, n0);
   }
 #undef LOAD_TILES
 #undef STORE_TILES
@@ -1177,7 +1246,8 @@ int pre_launch(const hands_conv_desc* d, const float* in, const float* pre_scale
 
 int splitk_launch(const hands_conv_desc* d, const float* in, const float* w_packed, const float* bias, const float* residual,
                   float* out, int S, float* workspace, long long workspace_floats,
-                  hands_stream_t stream, const float* pre_scale = nullptr, const float* pre_shift = nullptr) {
+                  hands_stream_t stream, const float* pre_scale = nullptr, const float* pre_shift = nullptr,
+                  int* counters = nullptr, long long n_counters = 0) {
   if (!d) return HANDS_EINVAL;
   const bool pre = pre_scale != nullptr;
   if (pre && (!pre_shift || !pointwise_route_ok(d) || (d->act & HANDS_MATH_BF16X3))) return HANDS_EINVAL;
@@ -1200,6 +1270,12 @@ int splitk_launch(const hands_conv_desc* d, const float* in, const float* w_pack
   a.relu = HANDS_ACT_NONE;
   a.ksplit = S; a.partial = workspace; a.part_ps = part_ps;
   a.in2 = in; a.K0 = 1 << 30; a.H2 = a.W2 = a.stride2 = a.in2_ps = 0;
+  {
+    // fused reduction when the caller's counter array covers the tiles of the instantiation this launch takes
+    const bool narrow = d->Cout <= 64 && !f64;
+    const long long ntiles = narrow ? ((M + 255) / 256) * ((d->Cout + 63) / 64) : ((M + 127) / 128) * ((d->Cout + 127) / 128);
+    if (counters && n_counters >= ntiles) { a.counters = counters; a.fin_res = residual; a.fin_act = d->act & HANDS_ACT_MASK; }
+  }
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (pre) rc = launch_fp32<2, true>(d, a, s);
@@ -1207,6 +1283,7 @@ int splitk_launch(const hands_conv_desc* d, const float* in, const float* w_pack
   else if (pointwise_route_ok(d)) rc = launch_fp32<2>(d, a, s);
   else rc = launch_fp32<0>(d, a, s);
   if (rc) return rc;
+  if (a.counters != nullptr) return 0;                  // the last slice of every tile has reduced it
   if (f64) {
     hipLaunchKernelGGL(splitk_reduce_f64_kernel, dim3(hands_grid_1d(M * d->Cout, 256)), dim3(256), 0, s,
                        reinterpret_cast<const double*>(workspace), S, (int)M, d->Cout, part_ps, bias, residual, d->res_pix_stride,
@@ -1250,6 +1327,14 @@ extern "C" int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const fl
                                               const float* bias, const float* residual, float* out, int S,
                                               float* workspace, long long workspace_floats, hands_stream_t stream) {
   return splitk_launch(d, in, w_packed, bias, residual, out, S, workspace, workspace_floats, stream);
+}
+
+extern "C" int hands_conv2d_nhwc_splitk_fused_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
+                                                  const float* bias, const float* residual, float* out, int S,
+                                                  float* workspace, long long workspace_floats, int* counters,
+                                                  long long n_counters, hands_stream_t stream) {
+  return splitk_launch(d, in, w_packed, bias, residual, out, S, workspace, workspace_floats, stream, nullptr, nullptr, counters,
+                       n_counters);
 }
 
 extern "C" int hands_conv2d_nhwc_splitk_f32(const hands_conv_desc* d, const float* in, const float* w_packed,

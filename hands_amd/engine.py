@@ -63,6 +63,8 @@ class ConvEngine:
                                       # v_mfma_f64_16x16x4_f64, correctly rounded fp32 outputs, half the fp32 matrix rate) -- ONE plain
                                       # direct launch, never Winograd / split-K / stream-K / blocked.  HandOccNet marks its heat-map head,
                                       # encoder and MLPs (DESIGN.md "Conditioning note"); False = those layers take the fp32 routes
+        self.fuse_splitk_reduce = True  # split-K launches reduce inside the launch (the last slice of a tile to arrive adds the partial
+                                      # sums in slice order: hands_conv2d_nhwc_splitk_fused_f32, same bits); False = the reduce kernel
         self.group_launches = True    # conv_group(): independent pointwise layers of one kernel instantiation as ONE launch
                                       # (hands_conv2d_group_f32, bit-identical to the separate launches); False = one launch each
         self.last_acc64 = False       # the launch the hook is being called for accumulates in fp64
@@ -83,7 +85,7 @@ class ConvEngine:
     def clone_settings(self) -> "ConvEngine":
         e = ConvEngine()
         for k in ("use_splitk", "latency_mode", "overlap", "fuse_stem_pool", "fuse_downsample", "winograd", "winograd4", "fuse_mano", "fuse_pre", "stream_k", "math", "chain_limit",
-                  "chain_min_k", "chain_max_pix", "chain_skip_tokens", "chain_in_kernel", "acc64", "group_launches"):
+                  "chain_min_k", "chain_max_pix", "chain_skip_tokens", "chain_in_kernel", "acc64", "group_launches", "fuse_splitk_reduce"):
             setattr(e, k, getattr(self, k))
         return e
 
@@ -133,6 +135,19 @@ class ConvEngine:
                 torch.cuda.synchronize(dev)
             ws = table[key] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=dev)
         return ws
+
+    def _counters(self, L, dev, stream):
+        """The zeroed per-tile arrival counters of the fused split-K reduction: one array per (device, launch stream) -- launches
+        on different streams must not share it; every launch leaves it zero.  None under hipGraph capture (the zero fill of a new
+        array would have to be ordered before a launch on another stream inside the capture: those launches keep the reduce kernel)."""
+        if self._capturing(L, stream):
+            return None
+        key = (dev, stream, "ctr")
+        c = self._splitk_ws.get(key)
+        if c is None:
+            c = self._splitk_ws[key] = torch.zeros(16384, dtype=torch.int32, device=dev)
+            torch.cuda.current_stream(dev).synchronize()     # zero fill done before a side stream uses it
+        return c
 
     def conv(self, L, pc, x, B, H, W, out, relu, stream, res=None, in_ps=None, out_ps=None, res_ps=None,
              x_off=0, out_off=0, res_off=0, splitk=False, splitk_n=0, pre=None):
@@ -222,8 +237,14 @@ class ConvEngine:
             hook("begin", pc, B * Ho * Wo, stream, res is not None, kname)
         if S > 1:     # latency-bound GEMM: deterministic split-K with a per-stream workspace
             ws = self._workspace(L, x.device, stream, L.hands_conv2d_workspace_floats(C.byref(d), S))
-            check(L.hands_conv2d_nhwc_splitk_n_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias), rp, ptr(out, out_off),
-                                                   S, ptr(ws), ws.numel(), stream), "hands_conv2d_nhwc_splitk_n_f32")
+            ctr = self._counters(L, x.device, stream) if self.fuse_splitk_reduce else None
+            if ctr is not None:       # the last slice of a tile reduces it: no second launch (same bits)
+                check(L.hands_conv2d_nhwc_splitk_fused_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias), rp, ptr(out, out_off),
+                                                           S, ptr(ws), ws.numel(), ptr(ctr), ctr.numel(), stream),
+                      "hands_conv2d_nhwc_splitk_fused_f32")
+            else:
+                check(L.hands_conv2d_nhwc_splitk_n_f32(C.byref(d), ptr(x, x_off), ptr(pc.w), ptr(pc.bias), rp, ptr(out, out_off),
+                                                       S, ptr(ws), ws.numel(), stream), "hands_conv2d_nhwc_splitk_n_f32")
         elif use_sk:
             key = (x.device, stream)
             sk = self._sk_ws.get(key)
@@ -355,7 +376,7 @@ class _GroupPC:
         self.group_bytes = sum(4.0 * (j["_npix"] * j["pc"].Cout * (2 if j.get("res") is not None else 1)
                                       + j["_npix"] * j["pc"].stride ** 2 * j["pc"].Cin + j["pc"].w.numel()) for j in chunk)
         pc0 = chunk[0]["pc"]
-        self.Cin, self.Cout, self.KH, self.stride, self.w = pc0.Cin, pc0.Cout, 1, pc0.stride, pc0.w
+        self.Cin, self.Cout, self.KH, self.stride, self.w, self.Kpad = pc0.Cin, pc0.Cout, 1, pc0.stride, pc0.w, pc0.Kpad
         self.macs_per_pixel = self.group_macs / max(self.npix, 1)
         self.members = len(chunk)
 

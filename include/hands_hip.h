@@ -178,6 +178,15 @@ int hands_conv2d_nhwc_splitk_f32(const hands_conv_desc* d, const float* in, cons
 int hands_conv2d_nhwc_splitk_n_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
                                    const float* bias, const float* residual, float* out, int S,
                                    float* workspace, long long workspace_floats, hands_stream_t stream);
+/* The same with the reduction FUSED into the launch (round 6): `counters` = n_counters ints, zero before the first call and left
+ * zero by every call (one array per stream: concurrent launches must not share it).  The slice of a tile that arrives last adds
+ * the partial sums in ascending slice order and applies bias / residual / activation -- the output bits of the two-launch form,
+ * one launch.  n_counters below the launch's tile count (ceil(M / 128) * ceil(Cout / 128), or ceil(M / 256) for Cout <= 64):
+ * falls back to the two launches. */
+int hands_conv2d_nhwc_splitk_fused_f32(const hands_conv_desc* d, const float* in, const float* w_packed,
+                                       const float* bias, const float* residual, float* out, int S,
+                                       float* workspace, long long workspace_floats, int* counters,
+                                       long long n_counters, hands_stream_t stream);
 
 /* Pointwise layer (1x1, no padding) whose INPUT first goes through a per-channel affine + LeakyReLU(0.01):
  *     out = act( bias + W . leaky_relu(in * pre_scale[c] + pre_shift[c]) (+ residual) )

@@ -1049,6 +1049,57 @@ def test_in_kernel_blocked_summation(case, limit):
         assert (via_splitk - blocked).abs().max().item() <= 4e-6 * max(1.0, ref.abs().max().item())
 
 
+FUSED_SPLITK_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, act, residual, S, acc64
+    (256, 2160, 1, 1, 1024, 1, 1, 0, 1, False, 8, False),     # an HMR refine layer at bz = 256 (2 x 8 tiles x 8 slices)
+    (37, 1024, 1, 1, 112, 1, 1, 0, 0, True, 4, False),        # the stacked decoders: partial m- and n-tile, residual
+    (5, 512, 9, 7, 72, 3, 1, 1, 3, True, 5, False),           # a 3x3 layer, odd sizes, S not a power of two
+    (300, 256, 1, 1, 64, 1, 1, 0, 2, False, 2, False),        # the narrow (256 x 64) tile, GELU
+    (70, 1024, 1, 1, 1024, 1, 1, 0, 3, False, 4, True),       # fp64 accumulation: fp64 partial sums
+    (3, 512, 6, 6, 136, 1, 1, 0, 1, True, 3, True),
+]
+
+
+@pytest.mark.parametrize("case", FUSED_SPLITK_CASES)
+def test_fused_splitk_reduction_equals_the_reduce_kernel(case):
+    """engine.fuse_splitk_reduce (hands_conv2d_nhwc_splitk_fused_f32): the slice of a tile that arrives last adds the partial sums
+    in ascending slice order and applies bias / residual / activation.  The same bits as split-K + splitk_reduce_kernel, for every
+    arrival order (repeated launches), with the counters left zero -- and an in-place residual (the HMR state row) works."""
+    B, Cin, H, W, Cout, k, stride, pad, act, use_res, S, acc64 = case
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(sum(int(v) for v in case))
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    pc = pack_conv(w, torch.randn(Cout, generator=g), stride, pad, DEV)
+    pc.acc64 = acc64
+    x = torch.randn(B, H, W, Cin, generator=g).to(DEV)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Ho, Wo, pc.Cout, generator=g).to(DEV) if use_res else None
+
+    def run(fused, eng=None, out=None, rs=res):
+        eng = eng or ConvEngine()
+        eng.winograd = False
+        eng.fuse_splitk_reduce = fused
+        out = out if out is not None else torch.full((B, Ho, Wo, pc.Cout), float("nan"), device=DEV)
+        eng.conv(L, pc, x, B, H, W, out, act, _stream(), res=rs, splitk_n=S)
+        return out, eng
+
+    two, _ = run(False)
+    one, eng = run(True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(one).all() and torch.equal(one, two)
+    ctr = eng._counters(L, x.device, _stream())
+    assert int(ctr.abs().sum().item()) == 0                       # every tile's counter is back at zero
+    for _ in range(5):                                            # other arrival orders, same engine (same counters): same bits
+        again, _ = run(True, eng)
+        assert torch.equal(again, two)
+    assert int(ctr.abs().sum().item()) == 0
+    if use_res:                                                   # in place: out aliases the residual
+        buf = res.clone()
+        inplace, _ = run(True, eng, out=buf, rs=buf)
+        torch.cuda.synchronize()
+        assert torch.equal(inplace, two)
+
+
 def test_summation_flags_are_exclusive_and_chain_in_kernel_rejects_other_lengths():
     """desc.act carries at most ONE summation form: both block flags, or a block flag with HANDS_MATH_BF16X3, are an invalid
     descriptor (HANDS_EINVAL = 10001, nothing launched); engine.chain_in_kernel with a block length the kernel has no
