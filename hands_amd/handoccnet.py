@@ -131,7 +131,7 @@ class HandOccNet(EngineSwitches, nn.Module):
         self.small_map_splitk = False  # True / "deep" / "16x16": call-site constant split-K on maps of <= 8x8 pixels and on the
                                        # one-tile 16x16 layers (see _conv_fns).  Off since round 5: with three forwards in flight the
                                        # chip is filled by other forwards, and the reduce launches cost more than the slices gain
-                                       # (tools/ab_small_map_splitk.py: +2.3 % at 32 samples, +2.9 % at 256); True shortens ONE
+                                       # (tools/experiments/ab_small_map_splitk.py: +2.3 % at 32 samples, +2.9 % at 256); True shortens ONE
                                        # synchronous forward at 2 samples by 6 % (6.5 against 6.9 ms)
         self.chunks = 2   # a forward that runs ALONE (async_forward off) splits its 2*bz crops into this many jobs on separate HIP
                           # streams (1 = single stream); pipelined forwards run one job each
@@ -543,7 +543,7 @@ class HandOccNet(EngineSwitches, nn.Module):
         main = torch.cuda.current_stream(dev)
         # measured (bz=32 -> 64 crops): 2 chunks without split-K lose 8 % (smaller launches), with
         # latency_mode they gain 4 %; at 512 crops they gain 3 %
-        # round 5, several forwards in flight (tools/ab_pipeline_depth.py): the other forwards fill the chip and one job per
+        # round 5, several forwards in flight (tools/experiments/ab_pipeline_depth.py): the other forwards fill the chip and one job per
         # forward is 0.6-1.4 % faster at 512 crops -- the crop jobs are for a forward that runs alone
         nch = self.chunks if (dbg is None and self.engine.overlap and not pipelined
                               and (B2 >= 128 or self.engine.latency_mode)) else 1

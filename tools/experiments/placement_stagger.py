@@ -9,7 +9,7 @@ import sys
 import time
 import types
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("HANDS_SYNTHETIC_MANO", "1")
 import numpy as np
 import torch

@@ -40,7 +40,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import csrc_sha16      # hash of the kernel sources: bench.py uses a stored summary only for the binary it was taken with
 
-res = {"workload": workload, "bz": bz, "csrc_sha16": csrc_sha16(), "kernel": "conv_igemm_f32_kernel + conv_igemm_sk_f32_kernel + conv_wino_f32_kernel", "dispatches": nf,
+res = {"workload": workload, "bz": bz, "csrc_sha16": csrc_sha16(), "kernel": "conv_igemm_f32_kernel + conv_igemm_group_f32_kernel + conv_igemm_sk_f32_kernel + conv_wino_f32_kernel + conv_wino4_f32_kernel (every dispatch whose name contains conv_igemm or conv_wino)", "dispatches": nf,
        "fetch_size_kb_sum": f, "write_size_kb_sum": w, "fetch_correction": 2.0,
        "hbm_gb_per_launch": (2.0 * f + w) * 1024 / nf / 1e9,
        "read_gb_per_launch": 2.0 * f * 1024 / nf / 1e9, "write_gb_per_launch": w * 1024 / nf / 1e9,

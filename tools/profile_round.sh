@@ -9,7 +9,7 @@ if [ "$BZ" = "0" ]; then case $WL in hamer_light) BZ=64;; handoccnet_light) BZ=2
 O=$R/gpurun_out/$TAG/${WL}_bz$BZ
 mkdir -p $O
 cd /tmp
-COMMON="--workload $WL --bz $BZ --no-cpu-baseline --no-also"
+COMMON="--workload $WL --bz $BZ --no-cpu-baseline --no-also --no-pmc"   # (the first, unprofiled run below takes the same-run traffic passes)
 python3 $R/bench.py --workload $WL --bz $BZ --no-also --layer-report $O/per_launch.csv > $O/bench_line.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -o serial -- python3 $R/bench.py $COMMON --serial --steps 5 --warmup 2 > $O/serial_bench_line.json 2> $O/serial.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/default -o default -- python3 $R/bench.py $COMMON --steps 5 --warmup 2 > $O/default_bench_line.json 2> $O/default.err
