@@ -530,3 +530,15 @@ def test_winograd_packer_layout_and_identity():
             y[:, :, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = np.einsum("ix,boxn,jn->boij", At, M, At)
     ref = F.conv2d(x, w, padding=1).numpy()
     assert np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max()           # U is rounded to fp32 once
+
+
+def test_library_was_built_from_the_sources_in_the_tree():
+    """hands_csrc_sha16() (embedded by csrc/Makefile) == the same hash over the tree (bench.csrc_tree_sha16): the in-tree .so is not
+    stale.  bench.py validates stored counter summaries against the LOADED library's hash, so the two must agree for a
+    summary taken on this tree to be usable."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod_hash", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    L = _lib.lib()
+    assert L.hands_csrc_sha16().decode() == bench.csrc_tree_sha16() == bench.csrc_sha16()

@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HANDS_SYNTHETIC_MANO", "1")
 
 _W = {}
+_NO_F64_3X3 = False
 
 
 def _worker_init():
@@ -61,6 +62,9 @@ def wilson(k, n, z=1.96):
 
 
 def parse_arm(name):
+    global _NO_F64_3X3
+    _NO_F64_3X3 = name.endswith("+nf3")             # "+nf3": the 3x3 layers of the fp64 stages stay fp32
+    name = name[:-4] if _NO_F64_3X3 else name
     name, _, wst = name.partition("+w:")           # "+w:resnet.fpn": Winograd F(2x2) in these stages only (overrides the scope)
     name, _, blk = name.partition("+b:")           # "+b:fpn.fit.set": blocked summation in these stages only
     name, _, f64 = name.partition("+f:")           # "+f:reghead.encoder.mlp": stages accumulated in fp64
@@ -122,6 +126,7 @@ def main():
         scope, limit, min_k, max_pix, skip_tok, in_kernel, f64, blk, wst = parse_arm(name)
         m = hands_amd.apply_recipe(hands_amd.HandOccNet()).to("cuda").eval()
         m.acc64_stages = f64 if "ALL" not in f64 else frozenset(hands_amd.handoccnet.STAGES)
+        m.acc64_3x3 = not _NO_F64_3X3
         if blk is not None:
             m.block_stages = blk
         if wst is not None:
