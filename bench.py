@@ -71,7 +71,9 @@ def parse_args(argv=None):
                          "bit-identical mode at the 8-GPU shard size; config.timed_mode says so), eager otherwise; 0 forces eager")
     ap.add_argument("--layer-report", default="", help="write a per-launch CSV of the MFMA kernels here")
     ap.add_argument("--no-pmc", action="store_true",
-                    help="do not take the same-run rocprofv3 --pmc passes (roofline.traffic then comes from a stored summary)")
+                    help="do not take the same-run rocprofv3 --pmc passes (two child runs of two one-stream forwards each BEFORE the first GPU call "
+                         "of this process: 30-90 s per workload, up to 2 x 150 s); roofline.traffic then comes from a stored summary "
+                         "whose csrc_sha16 equals the loaded library's, or is null")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the profiled child: two one-stream forwards
     return ap.parse_args(argv)
 

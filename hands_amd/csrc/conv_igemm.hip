@@ -185,11 +185,16 @@ __device__ __forceinline__ void epilogue_full(const f32x16 (&acc)[2][2], float* 
 // partial sums in ASCENDING slice order whoever arrives last, then bias, residual, activation -- operation for operation what
 // splitk_reduce_kernel / splitk_reduce_f64_kernel do, so the output bits are those of the two-launch form.
 template <int BM, int BN, bool F64>
-__device__ __forceinline__ void splitk_fused_tail(const ConvArgs& a, int tile, int m0, int n0) {
-  __shared__ int s_last;
+__device__ __forceinline__ void splitk_fused_tail(const ConvArgs& a, float* lds, int tile, int m0, int n0, int wave_u) {
+  // thread id from the wave index (an SGPR the caller saved before the tile) and mbcnt: reading threadIdx.x here would keep v0
+  // alive through the whole tile -- one register too many for the 256 x 64 tile's four workgroups per CU
+  const int tid = wave_u * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  // (the flag lives in the first word of the staging ring, idle by now: a __shared__ int of its own made the 256 x 64 tile's
+  //  40 KB ring 40 964 bytes = three workgroups per CU instead of four)
+  volatile int& s_last = *reinterpret_cast<volatile int*>(lds);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's partial stores have left
-  __syncthreads();
-  if (threadIdx.x == 0) {
+  __syncthreads();                                      // ... and every wave is done with the transposition buffers
+  if (tid == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int old = __hip_atomic_fetch_add(a.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -200,7 +205,6 @@ __device__ __forceinline__ void splitk_fused_tail(const ConvArgs& a, int tile, i
   __syncthreads();
   if (!s_last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  const int tid = threadIdx.x;
   const size_t slice = (size_t)a.M * a.part_ps;
   if constexpr (F64) {
     const double* part = reinterpret_cast<const double*>(a.partial);
@@ -259,6 +263,16 @@ constexpr int SK_SLOT_FLOATS = 4 * 64 * 64;   // one workgroup's accumulators: 4
 // BLK > 0 (8 or 4 k-steps = 128 / 64 floats): blocked summation -- after every BLK k-steps the accumulators are added to a
 // second set and cleared, so no fp32 FMA chain is longer than the block (HANDS_SUM_BLOCK*; 64 more registers: these
 // instantiations run two workgroups per CU instead of four).
+__device__ __forceinline__ void tile_coords(const ConvArgs& a, int tile, int& mt, int& nt) {
+  constexpr int RASTER_GM = 8;
+  if (a.nblk_n >= 8 && a.nblk_m >= RASTER_GM) {
+    const int per = RASTER_GM * a.nblk_n;
+    const int gidx = tile / per, idx = tile - gidx * per;
+    const int gm = min(RASTER_GM, a.nblk_m - gidx * RASTER_GM);
+    nt = idx / gm; mt = gidx * RASTER_GM + (idx - nt * gm);
+  } else { mt = tile / a.nblk_n; nt = tile - mt * a.nblk_n; }
+}
+
 template <int WAVES_M, int WAVES_N, int MODE, int PREC = 0, bool PRE = false, int BLK = 0>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int tile, int split, int kt0, int kt1,
                                           const float* acc_in, float* acc_out) {
@@ -287,14 +301,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
   // 8 x 16 block of the output (24 operand panels) instead of 4 m-rows x all n-tiles (34+): measured on hamer_light
   // bz=64: fabric reads per GEMM launch 2.50 -> 2.04 GB, speed unchanged (the Infinity Cache serves the re-reads
   // either way); hands_light / handoccnet_light neutral.  Any bijection gives the same output bits.
-  constexpr int RASTER_GM = 8;
   int mt, nt;
-  if (a.nblk_n >= 8 && a.nblk_m >= RASTER_GM) {
-    const int per = RASTER_GM * a.nblk_n;
-    const int gidx = tile / per, idx = tile - gidx * per;
-    const int gm = min(RASTER_GM, a.nblk_m - gidx * RASTER_GM);
-    nt = idx / gm; mt = gidx * RASTER_GM + (idx - nt * gm);
-  } else { mt = tile / a.nblk_n; nt = tile - mt * a.nblk_n; }
+  tile_coords(a, tile, mt, nt);
   const int m0 = mt * BM, n0 = nt * BN;
 
   // ---- per-thread staging assignment: row = (tid>>2) + 64*i, 16-byte chunk = tid&3 ------------
@@ -704,7 +712,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
             const int m = m0 + wm * 64 + 16 * jb + (lane & 15);
             if (m < a.M && ch < a.N) pd[(size_t)m * a.part_ps + ch] = accd[i][jb][r];
           }
-      if (a.counters != nullptr) splitk_fused_tail<BM, BN, true>(a, tile, m0, n0);
       return;
     }
   }
@@ -752,9 +759,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* lds, int til
       if (m < a.M && n_ok) *reinterpret_cast<float4*>(obase + (size_t)m * ops + n_lane) = v;
     }
   }
-  if constexpr (!F64) {
-    if (part && a.counters != nullptr) splitk_fused_tail<BM, BN, false>(a, tile, m0, n0);
-  }
 #undef LOAD_TILES
 #undef STORE_TILES
 }
@@ -770,7 +774,13 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(ConvArgs a) {
   const int nk_all = a.Kpad / BK;
   const int kt0 = a.ksplit > 1 ? (int)((long long)split * nk_all / a.ksplit) : 0;
   const int kt1 = a.ksplit > 1 ? (int)((long long)(split + 1) * nk_all / a.ksplit) : nk_all;
+  const int wave_u = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   conv_tile<WAVES_M, WAVES_N, MODE, PREC, PRE, BLK>(a, lds, tile, split, kt0, kt1, nullptr, nullptr);
+  if (a.ksplit > 1 && a.counters != nullptr) {          // fused split-K reduction: outside conv_tile, nothing of the tile is live here
+    int mt, nt;
+    tile_coords(a, tile, mt, nt);
+    splitk_fused_tail<64 * WAVES_M, 64 * WAVES_N, PREC == 2>(a, lds, tile, mt * 64 * WAVES_M, nt * 64 * WAVES_N, wave_u);
+  }
 }
 
 // ---- grouped launch: up to GROUP_MAX independent pointwise layers of ONE kernel instantiation in one launch ----------------

@@ -27,7 +27,6 @@
 // convolution is ~20x larger (tools/winograd_f43_parity.py: 4e-5 at output scale 4) while the end-to-end vertex error of
 // hands_light stays at 1e-7 m.  HandOccNet keeps F(2x2) (DESIGN.md "Conditioning note").
 #include <hip/hip_runtime.h>
-#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 #include "hands_hip.h"
@@ -254,6 +253,9 @@ __global__ void __launch_bounds__(1024, 1) conv_wino4_f32_kernel(Wino4Args a) {
       const int hy = 4 * ty - 1 + ar, wx = 4 * (tx0 + pv * D) - 1 + x;
       const bool ok = i < G::PIECES && x < G::PW && Rr < a.rows && (unsigned)hy < (unsigned)a.H && (unsigned)wx < (unsigned)a.W;
       f_off[j] = ok ? (((db * a.H + hy) * a.W + wx) * a.in_ps + q * 4) * 4 : (int)0x80000000u;
+      // stage 0's piece leaves as soon as its offset exists (round 6: the fills used to wait for all NJ offsets, ~2 k cycles of a
+      // 14 k prologue during which nothing else runs on the CU)
+      if (i < G::PIECES) w4_dma16(x_rsrc, sP + i * 1024, f_off[j], 0);
     }
 #define W4_PFILL(PB, G_)                                                                             \
   do {                                                                                              \
@@ -261,7 +263,6 @@ __global__ void __launch_bounds__(1024, 1) conv_wino4_f32_kernel(Wino4Args a) {
       if (j * 4 + pw < G::PIECES) w4_dma16(x_rsrc, sP + (PB) * W4_VBUF + (j * 4 + pw) * 1024, f_off[j], (G_) * 32); \
     }                                                                                               \
   } while (0)
-    W4_PFILL(0, 0);
     if (nsteps > 1) W4_PFILL(1, 1);
     // this lane's (tile, channel) of the transform: tile pw * 8 + (lane >> 3), channel lane & 7
     int tb[6];
@@ -379,6 +380,50 @@ __global__ void __launch_bounds__(1024, 1) conv_wino4_f32_kernel(Wino4Args a) {
     // A consumer's barrier is a bare s_barrier: its weight fragments stay in flight across it (__syncthreads() would wait for
     // them -- the last one is requested right before the barrier); only its LDS reads are drained.
 #define W4_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
+    if constexpr (NOB == 2) {
+      // 64 output channels per workgroup (round 6): 96 accumulator registers leave room for TWO weight-fragment sets (2 x 8
+      // registers: the next frequency's weights are requested from L2 under the current one's 8 MFMAs) and ONE V fragment (4
+      // registers, read from LDS right before its MFMAs: ~100 cycles that the SIMD's two other consumer waves cover).  Per stage
+      // the matrix pipe works twice as long for the same fill + transform: the producers stop being the stage's critical path.
+#define W4_V2(N, VP) do { vq[0] = *reinterpret_cast<const float4*>((VP) + (N) * 1024); } while (0)
+#define W4_MFMAS2(WSET, N)                                                                           \
+  do {                                                                                              \
+    _Pragma("unroll") for (int o = 0; o < NOB; ++o)                                                 \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                 \
+        acc[N][o] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4_e(wq[WSET][o], t), w4_e(vq[0], t), acc[N][o], 0, 0, 0); \
+  } while (0)
+      // ONE stage body (the register allocator gives two unrolled copies different accumulator registers and spills between them):
+      // frequency 0 and 2 use weight set 0, frequency 1 set 1.  The next stage's frequency-0 weights are requested into set 0 as
+      // soon as frequency 2's MFMAs have issued (they read their operands at issue) and stay in flight across the barrier.
+      W4_LOADW(0, 0, 0);                                       // frequency 0 of stage 0
+      W4_BARRIER();                                            // stage 0 (and 1) of the patch has landed
+      W4_BARRIER();                                            // V of stage 0 is written
+      W4_STAMP(0, 1);
+      for (int g = 0; g < nsteps; ++g) {
+        const int gn = g + 1 < nsteps ? g + 1 : g;              // (the last stage re-loads a valid step: no branch)
+        const char* vp = sV + (g & 1) * W4_VBUF + v_off;
+        W4_V2(0, vp); W4_LOADW(1, 1, g);
+        __builtin_amdgcn_sched_barrier(0);
+        W4_MFMAS2(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        W4_LOADW(0, 2, g);                                      // set 0 is free: frequency 0's MFMAs have issued
+        W4_V2(1, vp);
+        __builtin_amdgcn_sched_barrier(0);
+        W4_MFMAS2(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        W4_V2(2, vp);
+        __builtin_amdgcn_sched_barrier(0);
+        W4_MFMAS2(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        W4_LOADW(0, 0, gn);                                     // next stage, frequency 0
+        __builtin_amdgcn_sched_barrier(0);
+        W4_STAMP(0, 2 + 3 * g);
+        W4_BARRIER();
+        W4_STAMP(0, 4 + 3 * g);
+      }
+#undef W4_MFMAS2
+#undef W4_V2
+    } else {
     W4_LOADW(0, 0, 0);                                         // frequency 0 of stage 0 (its V fragment follows the barriers)
     W4_BARRIER();                                              // stage 0 (and 1) of the patch has landed
     W4_BARRIER();                                              // V of stage 0 is written
@@ -433,6 +478,7 @@ __global__ void __launch_bounds__(1024, 1) conv_wino4_f32_kernel(Wino4Args a) {
       W4_STAMP(0, 4 + 3 * g);
       vq[0] = *reinterpret_cast<const float4*>(sV + ((g + 1) & 1) * W4_VBUF + v_off);
     }
+    }
 #undef W4_BARRIER
 #undef W4_LOADOP
 #undef W4_LOADW
@@ -442,8 +488,11 @@ __global__ void __launch_bounds__(1024, 1) conv_wino4_f32_kernel(Wino4Args a) {
     //      hh = 0 (nu 0 1 2): P0 = M0 + M1 + M2, P1 = M1 - M2, P2 = M1 + M2;   hh = 1 (nu 3 4 5): P0 = M3 + M4, P1 = M3 - M4, P2 = M5
     //      and hands 32 channels at a time over through the whole LDS (every stage buffer is idle now): 8 channels per 36 KB region,
     //      block (xi, hh, p) at frequency slot f0 + p.  Accumulator register r of a lane: channel 8 (r >> 2) + 4 half + (r & 3).
+#define W4_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
 #pragma unroll
     for (int o = 0; o < NOB; ++o) {
+      // (fold and hand-over per 32-channel block: with both blocks folded up front the two sides of the hh branch held all 96
+      //  accumulators and the allocator spilled 64 of them around the first output pass)
       if (hh == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -457,17 +506,16 @@ __global__ void __launch_bounds__(1024, 1) conv_wino4_f32_kernel(Wino4Args a) {
           acc[0][o][r] = s_; acc[1][o][r] = d_;
         }
       }
-    }
-#pragma unroll
-    for (int o = 0; o < NOB; ++o) {
-      if (o > 0) __syncthreads();                              // the output pass of the previous 32 channels has read the LDS
+      // the output pass of the previous 32 channels has read the LDS.  Bare barriers behind the LDS traffic only: __syncthreads()
+      // would also wait for that pass's global stores to drain (vmcnt(0))
+      if (o > 0) W4_LDS_BARRIER();
 #pragma unroll
       for (int rd = 0; rd < 4; ++rd)
 #pragma unroll
         for (int n = 0; n < 3; ++n)
           *reinterpret_cast<float4*>(lds + rd * W4_VBUF + v_off + n * 1024) =
               make_float4(acc[n][o][4 * rd + 0], acc[n][o][4 * rd + 1], acc[n][o][4 * rd + 2], acc[n][o][4 * rd + 3]);
-      __syncthreads();
+      if (NOB > 1) W4_LDS_BARRIER(); else __syncthreads();
       W4_STAMP(0, 60);
       w4_output_pass<D, LINEAR, VSH>(a, lds, wave, lane, nb + o, R0, s0, tx0);
     }
@@ -477,8 +525,8 @@ __global__ void __launch_bounds__(1024, 1) conv_wino4_f32_kernel(Wino4Args a) {
   // ---- producers join the output passes (they hold no accumulators; the barrier sequence matches the consumers') --------------
 #pragma unroll
   for (int o = 0; o < NOB; ++o) {
-    if (o > 0) __syncthreads();
-    __syncthreads();
+    if (o > 0) W4_LDS_BARRIER();
+    if (NOB > 1) W4_LDS_BARRIER(); else __syncthreads();
     W4_STAMP(1, 60);
     w4_output_pass<D, LINEAR, VSH>(a, lds, wave, lane, nb + o, R0, s0, tx0);
   }
@@ -486,18 +534,6 @@ __global__ void __launch_bounds__(1024, 1) conv_wino4_f32_kernel(Wino4Args a) {
 }
 
 }  // namespace
-
-static int w4_device_cus() {
-  static std::atomic<int> cus[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  int n = cus[dev].load(std::memory_order_relaxed);
-  if (n == 0) {
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cus[dev].store(n, std::memory_order_relaxed);
-  }
-  return n;
-}
 
 static void w4_magic(int d, uint32_t& mul, uint32_t& sh) {
   if (d <= 1) { mul = 0; sh = 0; return; }
@@ -531,8 +567,10 @@ static int w4_launch_nob(Wino4Args& a, hipStream_t stream) {
     // a workgroup's weights: Cin / 8 stages x 36 KB per 32 channels
     const long long wbytes = (long long)(a.Cin / 8) * 36864 * NOB;
     long long band = W4_BAND_BYTES / wbytes;
-    const char* env = getenv("HANDS_W4_BAND");                   // dev override (tools/experiments): 1 = the round-5 order
+#ifdef HANDS_W4_BAND_ENV      // dev build only (tools/experiments/w4_band.py: EXTRA_FLAGS=-DHANDS_W4_BAND_ENV tools/build_variant.sh w4env):
+    const char* env = getenv("HANDS_W4_BAND");                   // HANDS_W4_BAND=1 is the round-5 order; the shipped library reads no environment
     if (env && atoi(env) > 0) band = atoi(env);
+#endif
     a.band = (int)(band < 1 ? 1 : (band > a.nblk_n ? a.nblk_n : band));
   }
   if (nblk_m <= 0 || nblk_m * a.nblk_n > 0x7fffffffLL) return HANDS_EINVAL;
@@ -547,9 +585,11 @@ static int w4_launch_nob(Wino4Args& a, hipStream_t stream) {
 
 template <int D, bool LINEAR, int VSH = 0>
 static int w4_launch(Wino4Args& a, hipStream_t stream) {
-  // NOB = 2 (64 output channels per workgroup: half the transform / fill work per MFMA) is what the stage profile asks for, but
-  // its 96 accumulator registers + operands do not fit the 128 registers a 16-wave workgroup leaves each wave: hipcc spills 170
-  // of them into the k-loop (round 5; the code path is kept, not instantiated).  See DESIGN.md "conv_wino4".
+  // NOB = 2 (64 output channels per workgroup: half the transform / fill work per MFMA) where the channel count allows it (round 6:
+  // 96 accumulator registers + two weight-fragment sets + one V fragment = 124 VGPRs, no spill in the k-loop); 32 otherwise.
+#ifndef HANDS_W4_NOB1        // (dev switch: -DHANDS_W4_NOB1 builds the round-5 form for A/B)
+  if (a.Cout % 64 == 0) return w4_launch_nob<D, LINEAR, VSH, 2>(a, stream);
+#endif
   return w4_launch_nob<D, LINEAR, VSH, 1>(a, stream);
 }
 

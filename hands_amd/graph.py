@@ -78,13 +78,13 @@ class GraphedForward:
         its first use; the caller may overwrite its inputs as soon as this returns."""
         i = self._calls % self.depth
         if self._hold[i] is not None:             # a consumer registered with hold_until() still reads this instance's outputs
-            torch.cuda.current_stream(self.dev).wait_event(self._hold[i])
-            self._hold[i] = None
-        self._last = i
+            torch.cuda.current_stream(self.dev).wait_event(self._hold[i])     # (the wait may stay even if the loads below raise)
         if self.depth == 1:
             self._load(self.static_in[0], inputs)
             self._load(self.static_meta[0], meta_info)
+            # bookkeeping only after both loads went through: a shape error leaves the slot, its hold and `_last` where they were
             self._calls += 1
+            self._hold[i], self._last = None, i
             self.graphs[0].replay()
             return self.static_out[0]
         main = torch.cuda.current_stream(self.dev)
@@ -92,7 +92,8 @@ class GraphedForward:
             main.wait_event(self._done[i])
         self._load(self.static_in[i], inputs)     # on the CALLER's stream: its tensors are free when we return
         self._load(self.static_meta[i], meta_info)
-        self._calls += 1                          # (a shape error above leaves the pipeline slot where it was)
+        self._calls += 1                          # (a shape error above leaves the pipeline slot, its hold and `_last` where they were)
+        self._hold[i], self._last = None, i
         ev = torch.cuda.Event()
         ev.record(main)
         st = self._streams[i]

@@ -74,6 +74,9 @@ CASES = [
     (33, 64, 8, 8, 64, 1),       # tile rows not a multiple of the block height
     (2, 24, 28, 28, 32, 1),      # Cin % 16 != 0 (8-channel stages)
     (3, 64, 55, 57, 64, 1),      # 14 x 15 tiles: linear geometry not applicable (nw = 15) -> D = 4
+    (2, 32, 26, 26, 32, 1),      # LINEAR geometry (nw = 7) with a PARTIAL last tile column (26 = 6 x 4 + 2) and a partial last tile row
+    (2, 32, 54, 55, 64, 3),      # LINEAR geometry with two virtual rows (nw = 14), width 55 = 13 x 4 + 3, height 54 = 13 x 4 + 2
+    (3, 64, 25, 27, 32, 0),      # nw = 7, width 27, height 25: the 4 otx + oj < W guard on three of four columns of the last tile
 ]
 
 
@@ -89,6 +92,19 @@ def test_winograd4_every_output_vs_fp64(case):
     scale = ref.abs().max().item()
     err = (got.double() - ref).abs().max().item()
     assert err <= TOL * scale, (case, err, scale)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 26, 27, 32), (2, 32, 54, 53, 64), (5, 64, 28, 28, 64)])
+def test_winograd4_linear_geometries_with_strided_layouts(case):
+    """The linear tile orders (7 and 14 tiles per row: the swizzled LDS-DMA fill and the per-column output guard) on maps whose
+    width is not a multiple of 4, through in / out pixel strides larger than the channel counts."""
+    B, Cin, H, W, Cout = case
+    x, w, bias = _case(B, Cin, H, W, Cout, sum(case))
+    pc = pack_conv(w, bias, 1, 1, DEV, winograd4=True)
+    got = _wino4(x, pc, 1, in_ps=Cin + 12, out_ps=Cout + 4)
+    assert torch.isnan(got[..., Cout:]).all()
+    ref = _ref(x, w, bias, 1)
+    assert (got[..., :Cout].double() - ref).abs().max().item() <= TOL * ref.abs().max().item()
 
 
 def test_winograd4_honours_pixel_strides_and_the_engine_routes_to_it():

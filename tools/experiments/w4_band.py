@@ -2,7 +2,9 @@
 """conv_wino4 workgroup order (round 6): band = 1 (round 5: channel block outermost) against the banded order, per trunk layer.
 Device time alternating in one process (HANDS_W4_BAND is read per launch), and -- under `rocprofv3 --pmc FETCH_SIZE` with
 --sequence -- ONE launch per (layer, band) in a fixed order so the counter rows can be matched.
-usage: python tools/experiments/w4_band.py [--sequence] [--images N]"""
+Needs a library built with -DHANDS_W4_BAND_ENV (the shipped one reads no environment):
+    EXTRA_FLAGS=-DHANDS_W4_BAND_ENV bash tools/build_variant.sh w4env -     (dev container)
+    HANDS_HIP_LIB=build_ab/w4env.so python tools/experiments/w4_band.py [--sequence] [--images N]     (GPU box)"""
 import ctypes as C
 import os
 import sys

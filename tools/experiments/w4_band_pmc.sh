@@ -1,5 +1,5 @@
 # usage (GPU box): bash tools/experiments/w4_band_pmc.sh   -> FETCH_SIZE / WRITE_SIZE per conv_wino4 launch, band 1 against the default
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; export HANDS_HIP_LIB=$R/build_ab/w4env.so   # built with -DHANDS_W4_BAND_ENV
 for CTR in FETCH_SIZE WRITE_SIZE; do
   O=/tmp/w4band_$CTR; rm -rf $O; mkdir -p $O; cd /tmp
   rocprofv3 --pmc $CTR --output-format csv -d $O -o f -- python3 $R/tools/experiments/w4_band.py --sequence > /dev/null 2> $O/err
