@@ -1136,6 +1136,24 @@ def compact_entry(full):
     return out
 
 
+ALSO_LIMIT = 2048
+
+
+def compact_also(full, key):
+    """One `also` line (stderr): the judged keys, below ALSO_LIMIT characters -- optional keys are shed, least important first
+    (everything is in gpurun_out/bench_details.json)."""
+    line = dict(compact_entry(full), also=key)
+    for drop in (("roofline", "by_bound"), ("cpu_baseline", "sample"), ("roofline", "kernel"), ("parity", "exceed_wilson95"),
+                 ("roofline", "dominant"), ("config", "conv3x3_stride1"), ("roofline", "traffic_source"), ("serial",)):
+        if len(json.dumps(line)) < ALSO_LIMIT:
+            break
+        d = line
+        for k in drop[:-1]:
+            d = d.get(k) or {}
+        d.pop(drop[-1], None)
+    return line
+
+
 def compact_headline(full, also=None, details_path=None):
     """THE stdout line: < HEADLINE_LIMIT characters, whatever the measurements returned."""
     line = compact_entry(full)
@@ -1271,7 +1289,7 @@ def main():
             # one short line per extra measurement -- on STDERR: stdout carries exactly ONE JSON line, the headline, so that
             # whichever line of stdout a harness parses (first, last, only) is the BASELINE metric on its config
             also[key] = r
-            sys.stderr.write(json.dumps(dict(compact_entry(r), also=key)) + "\n")
+            sys.stderr.write(json.dumps(compact_also(r, key)) + "\n")
             sys.stderr.flush()
 
         # name, bz, steps, warmup, parity bz.  *_bf16x3: separately reported arithmetic mode, never the headline value;

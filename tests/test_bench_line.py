@@ -129,3 +129,20 @@ def test_pin_rank_never_widens_or_empties_the_affinity(tmp_path):
         assert A.pin_rank_to_gpu_node(5, sysfs, env={}) == {"pinned": False, "why": "topology not in sysfs"}
     finally:
         os.sched_setaffinity(0, have)
+
+
+def test_also_lines_stay_below_their_limit(bench):
+    """Every `also` line (stderr) is < 2048 characters whatever the measurement carries: round 6 added the measured ceilings and the
+    per-thread-count parity sweep, and handoccnet_light's line reached 2233."""
+    full, also = canned()
+    for k, v in also.items():
+        v = dict(v)
+        v.setdefault("roofline", {}).update(peak_measured=155.2, frac_measured=0.87, hbm_measured_tbs=6.17, frac_on_own_roof_measured=0.89,
+                                            traffic_source="same-run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE child passes, 2 one-stream forwards each")
+        v["parity"] = dict(v.get("parity") or {}, oracle_threads=8, live_sweep_inside_bar=True,
+                           worst_by_oracle_threads={"8": 8.419e-07, "1": 4.917e-07, "16": 8.419e-07}, exceed_rate=0.0,
+                           exceed_wilson95=[0.0, 0.0038], exceed_n=1000, median_err_ratio_vs_fp64=0.78,
+                           exceed_source="stored: profiles/r06_hon_parity_ab_1000seeds_summary.json arm all+c64i+f:reghead.mlp" + "x" * 300)
+        line = bench.compact_also(v, k)
+        assert len(json.dumps(line)) < bench.ALSO_LIMIT == 2048, (k, len(json.dumps(line)))
+        assert line["also"] == k and line["value"] == v["value"] and "frac" in line["roofline"]
