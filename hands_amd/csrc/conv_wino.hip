@@ -267,6 +267,11 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
 
   // Stage s = (channel block s / nch, 16 channels s % nch) lives in buffer s & 1; its DMA and the weights of its first
   // step were issued one stage ahead -- also across the end of a channel block.  One barrier per stage (32 MFMAs per wave).
+#ifdef HANDS_WINO_FULL_BARRIERS      // A/B switch: the round-5 barriers
+#define WINO_LDS_BARRIER() __syncthreads()
+#else
+#define WINO_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
+#endif
   const int nch = a.Cin >> 4;
   const int nst = nch * a.nbw;
   __syncthreads();                       // (the compiler's fence waits for this wave's DMA)
@@ -310,7 +315,9 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
         }
         *reinterpret_cast<float4*>(sZ + xi * 1024 + zwr + (((2 * g + half) ^ (l31 & 7)) * 4)) = z;
       }
-      __syncthreads();
+      // LDS-only barriers in the two rounds (round 6): a __syncthreads() here also waits for the previous round's global stores and
+      // for the next stage's weights / DMA to land (vmcnt(0)) -- the stage barrier above and below is where those are needed
+      WINO_LDS_BARRIER();
       if (o_ok && (j == 0 || o_col1)) {
         const float4 z0 = *reinterpret_cast<const float4*>(sZ + 0 * 1024 + zpos);
         const float4 z1 = *reinterpret_cast<const float4*>(sZ + 1 * 1024 + zpos);
@@ -331,7 +338,7 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
         *reinterpret_cast<float4*>(o) = y0;
         if (o_row1) *reinterpret_cast<float4*>(o + (size_t)a.W * a.out_ps) = y1;
       }
-      __syncthreads();                    // round 1 reuses the region; after round 1 the next stage's DMA may overwrite it
+      WINO_LDS_BARRIER();                 // round 1 reuses the region; after round 1 the next stage's DMA may overwrite it
     }
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu)
@@ -339,6 +346,7 @@ __global__ void __launch_bounds__(256, WINO_WAVES) conv_wino_f32_kernel(WinoArgs
       for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
     ++nbi;
   }
+#undef WINO_LDS_BARRIER
 #undef WINO_STEP
 #undef WINO_LOADW
 #undef WINO_FILL

@@ -128,6 +128,8 @@ class HandOccNet(EngineSwitches, nn.Module):
         self.block_stages = frozenset(STAGES)   # stages whose direct launches sum in engine.chain_limit blocks (the others: single chains)
         self.wino_stages = None            # None: winograd_scope decides; else the stages whose 3x3 / s1 layers take Winograd F(2x2)
         self.acc64_stages = frozenset(("reghead", "mlp"))   # stages (STAGES) whose convolutions / linear layers accumulate in fp64
+        self.wino4_stages = frozenset()    # stages whose Winograd layers take F(4x4,3x3) instead of F(2x2) (needs engine.winograd4 = True;
+                                           # 10-20x F(2x2)'s per-layer rounding: off -- tools/hon_parity_ab.py arm "+w4:resnet")
         self.acc64_3x3 = True              # False: the 3x3 layers of the fp64 stages keep their fp32 route (Winograd / blocked direct)
         self.small_map_splitk = False  # True / "deep" / "16x16": call-site constant split-K on maps of <= 8x8 pixels and on the
                                        # one-tile 16x16 layers (see _conv_fns).  Off since round 5: with three forwards in flight the
@@ -187,7 +189,8 @@ class HandOccNet(EngineSwitches, nn.Module):
             sc = self.winograd_scope
             wino = stage_of(p) in self.wino_stages if self.wino_stages is not None else (sc == "all" or (sc == "trunk" and p.startswith("backbone.layer")) or
                     (sc in ("backbone", "backbone+fit") and p.startswith("backbone.")) or (sc == "backbone+fit" and p.startswith("FIT.")))
-            pc = pack_conv(w, b, stride, pad, dev, cin_pad_to=cin_pad_to, winograd=wino)
+            pc = pack_conv(w, b, stride, pad, dev, cin_pad_to=cin_pad_to, winograd=wino,
+                           winograd4=wino and stage_of(p) in self.wino4_stages)
             pc.acc64 = stage_of(p) in self.acc64_stages and (self.acc64_3x3 or w.shape[-1] == 1)
             pc.sum_block = -1 if stage_of(p) in self.block_stages else 0
             return pc

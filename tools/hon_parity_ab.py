@@ -25,6 +25,7 @@ os.environ.setdefault("HANDS_SYNTHETIC_MANO", "1")
 
 _W = {}
 _NO_F64_3X3 = False
+_W4_STAGES = frozenset()
 
 
 def _worker_init():
@@ -65,6 +66,9 @@ def parse_arm(name):
     global _NO_F64_3X3
     _NO_F64_3X3 = name.endswith("+nf3")             # "+nf3": the 3x3 layers of the fp64 stages stay fp32
     name = name[:-4] if _NO_F64_3X3 else name
+    global _W4_STAGES
+    name, _, w4 = name.partition("+w4:")           # "+w4:resnet": F(4x4,3x3) for the Winograd layers of these stages
+    _W4_STAGES = frozenset(x for x in w4.split(".") if x)
     name, _, wst = name.partition("+w:")           # "+w:resnet.fpn": Winograd F(2x2) in these stages only (overrides the scope)
     name, _, blk = name.partition("+b:")           # "+b:fpn.fit.set": blocked summation in these stages only
     name, _, f64 = name.partition("+f:")           # "+f:reghead.encoder.mlp": stages accumulated in fp64
@@ -127,6 +131,7 @@ def main():
         m = hands_amd.apply_recipe(hands_amd.HandOccNet()).to("cuda").eval()
         m.acc64_stages = f64 if "ALL" not in f64 else frozenset(hands_amd.handoccnet.STAGES)
         m.acc64_3x3 = not _NO_F64_3X3
+        m.wino4_stages, m.engine.winograd4 = _W4_STAGES, bool(_W4_STAGES)
         if blk is not None:
             m.block_stages = blk
         if wst is not None:
