@@ -54,10 +54,10 @@ typedef float f32x16""", "globals")
     s = sub(s, "  LOAD_TILES(kt0);\n  STORE_TILES(0);\n  __syncthreads();\n",
             "  const bool prof = threadIdx.x == 0 && blockIdx.x < 16384;\n  " + stamp("g_prof", 1) +
             "\n  LOAD_TILES(kt0);\n  STORE_TILES(0);\n  __syncthreads();\n  " + stamp("g_prof", 2) + "\n", "prologue")
-    s = sub(s, "  COMPUTE_STEP((kt1 - 1 - kt0) & 1);\n#undef COMPUTE_STEP\n",
-            "  COMPUTE_STEP((kt1 - 1 - kt0) & 1);\n#undef COMPUTE_STEP\n  " + stamp("g_prof", 3) + "\n", "loop end")
-    s = sub(s, "    return;\n  }\n  const float4 bv = part", "    " + stamp("g_prof", 4) + "\n    return;\n  }\n  const float4 bv = part",
-            "lean epilogue end")
+    s = sub(s, "  COMPUTE_STEP((kt1 - 1 - kt0) & 1);\n#ifdef HANDS_EPI_PRIO",
+            "  COMPUTE_STEP((kt1 - 1 - kt0) & 1);\n  " + stamp("g_prof", 3) + "\n#ifdef HANDS_EPI_PRIO", "loop end")
+    s = sub(s, "    return;\n  }\n  // PREC 2: the bias joins the fp64 sum", "    " + stamp("g_prof", 4) +
+            "\n    return;\n  }\n  // PREC 2: the bias joins the fp64 sum", "lean epilogue end")
     s = sub(s, "#undef LOAD_TILES\n#undef STORE_TILES\n}", "  " + stamp("g_prof", 4) + "\n#undef LOAD_TILES\n#undef STORE_TILES\n}",
             "general epilogue end")
     s = sub(s, "  const int ntiles = a.nblk_m * a.nblk_n;\n  const int split = a.ksplit > 1 ? blockIdx.x / ntiles : 0;\n",
