@@ -932,10 +932,32 @@ def stored_exceed_rate(workload, model):
         if getattr(model, "wino_stages", None) is not None or model.block_stages != frozenset(HON_STAGES):
             return {}                                        # a per-stage plan nobody ran the statistics for
         arm += "+f:" + ".".join(s_ for s_ in ("reghead", "encoder", "mlp", "fit", "set", "fpn", "resnet", "hourglass") if s_ in f64)
-        return pick(("r06_hon_parity_ab_1000seeds_summary.json",), arm)
+        res = pick(("r06_hon_parity_ab_1000seeds_summary.json",), arm)
+        if res and arm == "all+c64i+f:reghead.mlp":
+            res.update(live_thread_counts())
+        return res
     if not getattr(model, "small_map_splitk", False):       # the runs before `_e_` had the small-map split-K rules on
         return {}                                            # round-5 figures describe round-5 kernels (attention, softmax changed since)
     return {}
+
+
+def live_thread_counts():
+    """handoccnet_light, shipped default: inputs above 1e-6 m against the oracle run LIVE on a GPU box's host at 8 and at 1 ATen
+    threads, and the oracle at 8 threads against ITSELF at 1 (tools/hon_live_threads.py, seeds 3000-3249 and 4000-4999; STORED:
+    profiles/r06_hon_live_threads_*_summary.json).  The reference is not inside the bar against itself on every input."""
+    k = {"8": 0, "1": 0, "n": 0}
+    self_max = 0.0
+    for fn in ("r06_hon_live_threads_250seeds_summary.json", "r06_hon_live_threads_1000seeds_summary.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            k["8"] += d["hip_vs_t8"]["exceed"]
+            k["1"] += d["hip_vs_t1"]["exceed"]
+            k["n"] += d["n"]
+            self_max = max(self_max, d["ref_t8_vs_t1"]["max"])
+        except (OSError, ValueError, KeyError):
+            return {}
+    return {"exceed_live_box": {"vs_oracle_8_threads": f"{k['8']}/{k['n']}", "vs_oracle_1_thread": f"{k['1']}/{k['n']}",
+                                "oracle_8_vs_1_threads_max_m": float(f"{self_max:.3e}")}}
 
 
 def cpu_baseline_hands_light(ctx, model, sd_cpu):
@@ -1110,7 +1132,7 @@ ROOFLINE_KEYS = ("bound", "mode", "kernel", "achieved", "peak", "unit", "frac", 
 CPU_KEYS = ("value", "unit", "cores", "kind", "bz", "sample")
 PARITY_KEYS = ("mpjpe_vs_ref_mm", "max_vertex_err_m", "checked_hands", "oracle_threads", "worst_vertex_err_m", "worst_seed", "sweep_seeds",
                "bar_m", "live_sweep_inside_bar", "worst_by_oracle_threads", "exceed_rate", "exceed_wilson95", "exceed_n",
-               "median_err_ratio_vs_fp64", "exceed_source")
+               "median_err_ratio_vs_fp64", "exceed_source", "exceed_live_box")
 CONFIG_KEYS = ("workload", "per_gpu_batch", "global_batch", "parallelism", "rccl_ranks", "collective_backend", "launched_by",
                "timed_mode", "conv3x3_stride1", "steps", "warmup", "allgather_selfcheck_us")
 

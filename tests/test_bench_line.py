@@ -142,6 +142,7 @@ def test_also_lines_stay_below_their_limit(bench):
         v["parity"] = dict(v.get("parity") or {}, oracle_threads=8, live_sweep_inside_bar=True,
                            worst_by_oracle_threads={"8": 8.419e-07, "1": 4.917e-07, "16": 8.419e-07}, exceed_rate=0.0,
                            exceed_wilson95=[0.0, 0.0038], exceed_n=1000, median_err_ratio_vs_fp64=0.78,
+                           exceed_live_box={"vs_oracle_8_threads": "0/1250", "vs_oracle_1_thread": "1/1250", "oracle_8_vs_1_threads_max_m": 1.073e-06},
                            exceed_source="stored: profiles/r06_hon_parity_ab_1000seeds_summary.json arm all+c64i+f:reghead.mlp" + "x" * 300)
         line = bench.compact_also(v, k)
         assert len(json.dumps(line)) < bench.ALSO_LIMIT == 2048, (k, len(json.dumps(line)))
